@@ -1,0 +1,168 @@
+"""ctypes binding of libcapdec.so (the C ABI declared in include/capdec.h).
+
+There is no fallback: if the shared library is missing, or a call returns an
+error code, a RuntimeError is raised.  Tensors are passed as raw device
+pointers (``tensor.data_ptr()``); torch only owns the memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcapdec.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+MASK_NONE, MASK_REFERENCE, MASK_PREFIX_CAUSAL = 0, 1, 2
+GATE_NONE, GATE_RELU_OUT, GATE_GELU_PRE = 0, 1, 2
+ABI_VERSION = 1
+
+c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", c_float), ("key0", C.c_uint32), ("key1", C.c_uint32)]
+
+
+NO_DROPOUT = Dropout(0.0, 0, 0)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_long), ("ldb", c_long), ("ldc", c_long),
+        ("a_kmajor", c_int), ("b_kmajor", c_int),
+        ("in_dtype", c_int), ("out_dtype", c_int),
+        ("bias", c_void_p),
+        ("col_scale", c_float), ("col_scale_n", c_int),
+        ("act", c_int),
+        ("drop", Dropout),
+        ("residual", c_void_p), ("ldr", c_long),
+        ("accumulate", c_int),
+        ("gate", c_void_p), ("ldg", c_long), ("gate_mode", c_int), ("gate_dtype", c_int), ("gate_drop", Dropout),
+        ("aux_out", c_void_p), ("ldaux", c_long),
+        ("colsum", c_void_p),
+        ("kv_cache", c_void_p), ("kv_d", c_int), ("kv_B", c_int), ("kv_H", c_int), ("kv_hd", c_int),
+        ("kv_smax", c_int), ("kv_s0", c_int),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+        ("q_bs", c_long), ("q_hs", c_long), ("q_ss", c_long),
+        ("k_bs", c_long), ("k_hs", c_long), ("k_ss", c_long),
+        ("v_bs", c_long), ("v_hs", c_long), ("v_ss", c_long),
+        ("o_bs", c_long), ("o_hs", c_long), ("o_ss", c_long),
+        ("dtype", c_int),
+        ("B", c_int), ("H", c_int), ("S", c_int), ("hd", c_int),
+        ("q_start", c_int), ("nq", c_int),
+        ("mask_mode", c_int), ("prefix_len", c_int),
+        ("drop", Dropout),
+        ("lse", c_void_p),
+    ]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("fwd", AttnDesc),
+        ("dout", c_void_p), ("do_bs", c_long), ("do_hs", c_long), ("do_ss", c_long),
+        ("dq", c_void_p), ("dq_bs", c_long), ("dq_hs", c_long), ("dq_ss", c_long),
+        ("dk", c_void_p), ("dk_bs", c_long), ("dk_hs", c_long), ("dk_ss", c_long),
+        ("dv", c_void_p), ("dv_bs", c_long), ("dv_hs", c_long), ("dv_ss", c_long),
+        ("dq_scale", c_float),
+        ("delta", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/capdec.h declares
+SIGNATURES = {
+    "capdec_abi_version": (c_int, []),
+    "capdec_last_error": (C.c_char_p, []),
+    "capdec_dropout_mask": (c_int, [Dropout, c_long, c_void_p, c_void_p]),
+    "capdec_concat_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "capdec_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "capdec_ln_bwd_workspace": (c_long, [c_long, c_int]),
+    "capdec_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "capdec_gemm_bias_act": (c_int, [C.POINTER(GemmDesc), c_void_p]),
+    "capdec_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
+    "capdec_attn_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
+    "capdec_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "capdec_logits_ce_workspace": (c_long, [c_long, c_int]),
+    "capdec_logits_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
+                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_long, c_void_p]),
+    "capdec_logits_ce_bwd_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
+                                          c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int,
+                                          c_void_p, c_long, c_void_p, c_void_p]),
+    "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
+                                     c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "capdec_dropout_bwd_cast": (c_int, [c_void_p, c_long, c_int, Dropout, c_void_p, c_int, c_void_p, c_void_p]),
+    "capdec_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
+    "capdec_embed_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "capdec_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                                 c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "capdec_greedy_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_int64, C.c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libcapdec.so and bind every declared symbol.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.capdec_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libcapdec ABI {got} != binding ABI {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().capdec_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("image_caption_amd runs on an MI355X through libcapdec; got a CPU tensor "
+                               "(there is no CPU fallback)")

@@ -1,0 +1,690 @@
+// Self-attention for the captioning decoder (gfx950).
+//
+// Training / prefill (bf16): one workgroup per (sequence, head, 64-query slab);
+// the sequence's whole K and V ([S,hd], S <= 384) sit in LDS, each wave owns 16
+// queries and walks the keys in blocks of 64 with an online softmax.  Scores are
+// computed transposed (S^T = K Q^T) so that a lane holds 4 consecutive keys of
+// ONE query: the probabilities are then already the B operand of the next MFMA
+// (O^T = V^T P^T) and V^T comes from LDS through the transposing read; nothing
+// but K and V ever touches LDS.  The backward uses the same trick twice: a
+// query-major kernel for dQ and a key-major kernel for dK/dV, both recomputing
+// P from the saved log-sum-exp.
+// Validation (f32): simple exact-f32 kernels with the same interface.
+// Decoding: one query row against a contiguous K/V cache, HBM-bound.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* o;
+    long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_hs, o_ss;
+    int B, H, S, hd, q_start, nq, mask_mode, open_cols;
+    uint32_t drop_thr, drop_k0, drop_k1; float drop_scale;
+    float* lse;
+    // backward
+    const void* dout; long do_bs, do_hs, do_ss;
+    void* dq; long dq_bs, dq_hs, dq_ss;
+    void* dk; long dk_bs, dk_hs, dk_ss;
+    void* dv; long dv_bs, dv_hs, dv_ss;
+    float dq_scale; float* delta;
+};
+
+__device__ __forceinline__ bool key_visible(int q, int key, int S, int mask_mode, int open_cols) {
+    return key < S && (mask_mode == CAPDEC_MASK_NONE || key <= q || key < open_cols);
+}
+
+template <int HD> struct Geo {
+    static constexpr int ROWB = HD * 2 + 16;   // LDS bytes per row (16-B pad)
+    static constexpr int KS = HD / 32;         // 32-deep k-steps over the head dim
+    static constexpr int DT = HD / 16;         // 16-wide tiles over the head dim
+    static constexpr int CPR = HD / 8;         // 16-B chunks per row
+};
+
+// rows [row0, row0+nvalid) of a strided [*, HD] bf16 matrix -> LDS, zero rows up to npad
+template <int HD>
+__device__ __forceinline__ void rows_to_lds(char* lds, const bf16_t* base, long sstride, int row0, int nvalid, int npad,
+                                            int tid, int nthreads) {
+    constexpr int CPR = Geo<HD>::CPR, ROWB = Geo<HD>::ROWB;
+    for (int c = tid; c < npad * CPR; c += nthreads) {
+        const int row = c / CPR, ch = c - row * CPR;
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (row < nvalid) v = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * sstride + ch * 8);
+        *reinterpret_cast<u32x4*>(lds + row * ROWB + ch * 16) = v;
+    }
+}
+
+// row-major MFMA operand: lane (g,i) gets M[row0+i][k0 + 8g .. +7]
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * Geo<HD>::ROWB + (k0 + 8 * (lane >> 4)) * 2);
+}
+// transposed MFMA operand from a [row][col] LDS image: lane (g,i) gets
+//   { M[rA + 4g + 0..3][col0 + i], M[rB + 4g + 0..3][col0 + i] }
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_cols(const char* lds, int rA, int rB, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int off = (4 * g + (i >> 2)) * Geo<HD>::ROWB + (col0 + 4 * (i & 3)) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds + rA * Geo<HD>::ROWB + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds + rB * Geo<HD>::ROWB + off));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ bf16x8 zero_frag() {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)0.f;
+    return r;
+}
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// ================================================================== forward (bf16 MFMA)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<HD>;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int SP = (p.S + 63) & ~63;
+    char* Kl = smem;
+    char* Vl = smem + SP * G::ROWB;
+    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, 256);
+    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, 256);
+    __syncthreads();
+    const int qw = p.q_start + blockIdx.y * 64 + wave * 16;       // first query of this wave
+    const int qend = min(p.q_start + p.nq, p.S);
+    if (qw >= qend) return;
+    const int q = qw + i;
+    const bool qok = q < qend;
+    const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
+    bf16x8 qf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + 8 * g) : zero_frag();
+    f32x4 oacc[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+
+    for (int kb = 0; kb < SP; kb += 64) {
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s[t], 0, 0, 0);
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + t * 16 + 4 * g + r;
+                if (!key_visible(q, key, p.S, p.mask_mode, p.open_cols)) s[t][r] = -INFINITY;
+                bm = fmaxf(bm, s[t][r]);
+            }
+        bm = quad_max(bm);
+        const float m_new = fmaxf(m_run, bm);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
+        m_run = m_new;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = __expf(s[t][r] - m_use);
+                l_run += pv;
+                if (p.drop_thr) {
+                    const int key = kb + t * 16 + 4 * g + r;
+                    pv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? pv * p.drop_scale : 0.f;
+                }
+                pf[t >> 1][(t & 1) * 4 + r] = (bf16_t)pv;
+            }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    frag_cols<HD>(Vl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
+    }
+    const float l = quad_sum(l_run);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (qok) {
+        bf16_t* orow = (bf16_t*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[dt][r] * inv);
+            *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = o;
+        }
+        if (g == 0 && p.lse) p.lse[(long)bh * p.S + q] = m_run + __logf(l);
+    }
+}
+
+// ================================================================== backward: dQ (query-major)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<HD>;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int SP = (p.S + 63) & ~63;
+    char* Kl = smem;
+    char* Vl = smem + SP * G::ROWB;
+    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, 256);
+    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, 256);
+    __syncthreads();
+    const int qw = p.q_start + blockIdx.y * 64 + wave * 16;
+    const int qend = min(p.q_start + p.nq, p.S);
+    if (qw >= qend) return;
+    const int q = qw + i;
+    const bool qok = q < qend;
+    const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
+    const bf16_t* dorow = (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs + (long)q * p.do_ss;
+    bf16x8 qf[G::KS], dof[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + 8 * g) : zero_frag();
+        dof[ks] = qok ? *reinterpret_cast<const bf16x8*>(dorow + ks * 32 + 8 * g) : zero_frag();
+    }
+    const float lse = qok ? p.lse[(long)bh * p.S + q] : 0.f;
+    const float delta = qok ? p.delta[(long)bh * p.S + q] : 0.f;
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    f32x4 acc[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
+
+    for (int kb = 0; kb < SP; kb += 64) {
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 s = f32x4{0, 0, 0, 0}, dp = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Vl, kb + t * 16, ks * 32, lane), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + t * 16 + 4 * g + r;
+                const bool vis = qok && key_visible(q, key, p.S, p.mask_mode, p.open_cols);
+                const float pv = vis ? __expf(s[r] - lse) : 0.f;
+                float dpv = dp[r];
+                if (p.drop_thr) dpv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? dpv * p.drop_scale : 0.f;
+                dsf[t >> 1][(t & 1) * 4 + r] = (bf16_t)(pv * (dpv - delta));
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt)
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
+    }
+    if (qok) {
+        bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[dt][r] * p.dq_scale);
+            *reinterpret_cast<bf16x4*>(dqrow + dt * 16 + 4 * g) = o;
+        }
+    }
+}
+
+// ================================================================== backward: dK, dV (key-major)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<HD>;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int nq = min(p.nq, p.S - p.q_start);
+    const int NQP = (nq + 31) & ~31;
+    char* Ql = smem;
+    char* Dl = smem + NQP * G::ROWB;
+    float* lse_l = reinterpret_cast<float*>(smem + 2 * NQP * G::ROWB);
+    float* del_l = lse_l + NQP;
+    rows_to_lds<HD>(Ql, (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs, p.q_ss, p.q_start, nq, NQP, tid, 256);
+    rows_to_lds<HD>(Dl, (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs, p.do_ss, p.q_start, nq, NQP, tid, 256);
+    for (int c = tid; c < NQP; c += 256) {
+        lse_l[c] = c < nq ? p.lse[(long)bh * p.S + p.q_start + c] : 0.f;
+        del_l[c] = c < nq ? p.delta[(long)bh * p.S + p.q_start + c] : 0.f;
+    }
+    __syncthreads();
+    const int kw = blockIdx.y * 64 + wave * 16;
+    if (kw >= p.S) return;
+    const int key = kw + i;
+    const bool kok = key < p.S;
+    const bf16_t* krow = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs + (long)key * p.k_ss;
+    const bf16_t* vrow = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs + (long)key * p.v_ss;
+    bf16x8 kf[G::KS], vf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        kf[ks] = kok ? *reinterpret_cast<const bf16x8*>(krow + ks * 32 + 8 * g) : zero_frag();
+        vf[ks] = kok ? *reinterpret_cast<const bf16x8*>(vrow + ks * 32 + 8 * g) : zero_frag();
+    }
+    f32x4 dkacc[G::DT], dvacc[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) { dkacc[dt] = f32x4{0, 0, 0, 0}; dvacc[dt] = f32x4{0, 0, 0, 0}; }
+
+    for (int q0 = 0; q0 < NQP; q0 += 32) {
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 s = f32x4{0, 0, 0, 0}, dp = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Ql, q0 + t * 16, ks * 32, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Dl, q0 + t * 16, ks * 32, lane), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = q0 + t * 16 + 4 * g + r;       // local query row
+                const int qq = p.q_start + ql;
+                const bool vis = kok && ql < nq && key_visible(qq, key, p.S, p.mask_mode, p.open_cols);
+                const float pv = vis ? __expf(s[r] - lse_l[ql]) : 0.f;
+                float pd = pv, dpv = dp[r];
+                if (p.drop_thr) {
+                    const bool keep = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)((bh * p.S + qq) * (long)p.S) + key, p.drop_thr);
+                    pd = keep ? pv * p.drop_scale : 0.f;
+                    dpv = keep ? dpv * p.drop_scale : 0.f;
+                }
+                pf[t * 4 + r] = (bf16_t)pd;
+                dsf[t * 4 + r] = (bf16_t)(pv * (dpv - del_l[ql]));
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(Dl, q0, q0 + 16, dt * 16, lane), pf, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(Ql, q0, q0 + 16, dt * 16, lane), dsf, dkacc[dt], 0, 0, 0);
+        }
+    }
+    if (kok) {
+        bf16_t* dkrow = (bf16_t*)p.dk + b * p.dk_bs + h * p.dk_hs + (long)key * p.dk_ss;
+        bf16_t* dvrow = (bf16_t*)p.dv + b * p.dv_bs + h * p.dv_hs + (long)key * p.dv_ss;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+            bf16x4 a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dkacc[dt][r]; c[r] = (bf16_t)dvacc[dt][r]; }
+            *reinterpret_cast<bf16x4*>(dkrow + dt * 16 + 4 * g) = a;
+            *reinterpret_cast<bf16x4*>(dvrow + dt * 16 + 4 * g) = c;
+        }
+    }
+}
+
+// delta[bh][q] = sum_j do[q][j] * o[q][j]
+template <typename T>
+__global__ void attn_delta_kernel(AttnArgs p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.B * p.H * p.nq;
+    if (idx >= total) return;
+    const int h = idx % p.H;
+    const long sb = idx / p.H;
+    const int b = sb % p.B;
+    const int q = p.q_start + (int)(sb / p.B);
+    if (q >= p.S) return;
+    const T* o = (const T*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
+    const T* d = (const T*)p.dout + b * p.do_bs + h * p.do_hs + (long)q * p.do_ss;
+    float a = 0.f;
+    for (int j = 0; j < p.hd; ++j) a += to_f32<T>(o[j]) * to_f32<T>(d[j]);
+    p.delta[((long)b * p.H + h) * p.S + q] = a;
+}
+
+// ================================================================== exact-f32 validation kernels
+// one 64-thread block per (b, h, query)
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_simple(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    float* pr = qs + p.hd;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int q = p.q_start + blockIdx.y, lane = threadIdx.x;
+    if (q >= p.S) return;
+    const T* qrow = (const T*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
+    const T* kb = (const T*)p.k + b * p.k_bs + h * p.k_hs;
+    const T* vb = (const T*)p.v + b * p.v_bs + h * p.v_hs;
+    for (int j = lane; j < p.hd; j += 64) qs[j] = to_f32<T>(qrow[j]);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < p.S; key += 64) {
+        float s = -INFINITY;
+        if (key_visible(q, key, p.S, p.mask_mode, p.open_cols)) {
+            s = 0.f;
+            const T* kr = kb + (long)key * p.k_ss;
+            for (int j = 0; j < p.hd; ++j) s = fmaf(qs[j], to_f32<T>(kr[j]), s);
+        }
+        pr[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int key = lane; key < p.S; key += 64) {
+        const float e = pr[key] == -INFINITY ? 0.f : expf(pr[key] - mx);
+        sum += e;
+        pr[key] = e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    for (int key = lane; key < p.S; key += 64) {
+        float pv = pr[key] * inv;
+        if (p.drop_thr) pv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? pv * p.drop_scale : 0.f;
+        pr[key] = pv;
+    }
+    __syncthreads();
+    T* orow = (T*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
+    for (int j = lane; j < p.hd; j += 64) {
+        float a = 0.f;
+        for (int key = 0; key < p.S; ++key) a = fmaf(pr[key], to_f32<T>(vb[(long)key * p.v_ss + j]), a);
+        orow[j] = from_f32<T>(a);
+    }
+    if (lane == 0 && p.lse) p.lse[(long)bh * p.S + q] = mx + logf(sum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dq_simple(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    float* ds_ = qs + p.hd;
+    float* dos = ds_ + p.S;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int q = p.q_start + blockIdx.y, lane = threadIdx.x;
+    if (q >= p.S) return;
+    const T* qrow = (const T*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
+    const T* dorow = (const T*)p.dout + b * p.do_bs + h * p.do_hs + (long)q * p.do_ss;
+    const T* kb = (const T*)p.k + b * p.k_bs + h * p.k_hs;
+    const T* vb = (const T*)p.v + b * p.v_bs + h * p.v_hs;
+    for (int j = lane; j < p.hd; j += 64) { qs[j] = to_f32<T>(qrow[j]); dos[j] = to_f32<T>(dorow[j]); }
+    __syncthreads();
+    const float lse = p.lse[(long)bh * p.S + q], delta = p.delta[(long)bh * p.S + q];
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    for (int key = lane; key < p.S; key += 64) {
+        float dsv = 0.f;
+        if (key_visible(q, key, p.S, p.mask_mode, p.open_cols)) {
+            float s = 0.f, dp = 0.f;
+            const T* kr = kb + (long)key * p.k_ss;
+            const T* vr = vb + (long)key * p.v_ss;
+            for (int j = 0; j < p.hd; ++j) { s = fmaf(qs[j], to_f32<T>(kr[j]), s); dp = fmaf(dos[j], to_f32<T>(vr[j]), dp); }
+            if (p.drop_thr) dp = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? dp * p.drop_scale : 0.f;
+            dsv = expf(s - lse) * (dp - delta);
+        }
+        ds_[key] = dsv;
+    }
+    __syncthreads();
+    T* dqrow = (T*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
+    for (int j = lane; j < p.hd; j += 64) {
+        float a = 0.f;
+        for (int key = 0; key < p.S; ++key) a = fmaf(ds_[key], to_f32<T>(kb[(long)key * p.k_ss + j]), a);
+        dqrow[j] = from_f32<T>(a * p.dq_scale);
+    }
+}
+
+// one 64-thread block per (b, h, key)
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_simple(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ks_ = reinterpret_cast<float*>(smem);
+    float* vs_ = ks_ + p.hd;
+    float* pd_ = vs_ + p.hd;      // dropped probabilities per query
+    float* ds_ = pd_ + p.S;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int key = blockIdx.y, lane = threadIdx.x;
+    const T* krow = (const T*)p.k + b * p.k_bs + h * p.k_hs + (long)key * p.k_ss;
+    const T* vrow = (const T*)p.v + b * p.v_bs + h * p.v_hs + (long)key * p.v_ss;
+    const T* qb = (const T*)p.q + b * p.q_bs + h * p.q_hs;
+    const T* dob = (const T*)p.dout + b * p.do_bs + h * p.do_hs;
+    for (int j = lane; j < p.hd; j += 64) { ks_[j] = to_f32<T>(krow[j]); vs_[j] = to_f32<T>(vrow[j]); }
+    __syncthreads();
+    const int qend = min(p.q_start + p.nq, p.S);
+    for (int q = p.q_start + lane; q < qend; q += 64) {
+        float pd = 0.f, dsv = 0.f;
+        if (key_visible(q, key, p.S, p.mask_mode, p.open_cols)) {
+            float s = 0.f, dp = 0.f;
+            const T* qr = qb + (long)q * p.q_ss;
+            const T* dr = dob + (long)q * p.do_ss;
+            for (int j = 0; j < p.hd; ++j) { s = fmaf(to_f32<T>(qr[j]), ks_[j], s); dp = fmaf(to_f32<T>(dr[j]), vs_[j], dp); }
+            const float pv = expf(s - p.lse[(long)bh * p.S + q]);
+            pd = pv;
+            if (p.drop_thr) {
+                const bool keep = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)((bh * p.S + q) * (long)p.S) + key, p.drop_thr);
+                pd = keep ? pv * p.drop_scale : 0.f;
+                dp = keep ? dp * p.drop_scale : 0.f;
+            }
+            dsv = pv * (dp - p.delta[(long)bh * p.S + q]);
+        }
+        pd_[q] = pd; ds_[q] = dsv;
+    }
+    __syncthreads();
+    T* dkrow = (T*)p.dk + b * p.dk_bs + h * p.dk_hs + (long)key * p.dk_ss;
+    T* dvrow = (T*)p.dv + b * p.dv_bs + h * p.dv_hs + (long)key * p.dv_ss;
+    for (int j = lane; j < p.hd; j += 64) {
+        float a = 0.f, c = 0.f;
+        for (int q = p.q_start; q < qend; ++q) {
+            a = fmaf(ds_[q], to_f32<T>(qb[(long)q * p.q_ss + j]), a);
+            c = fmaf(pd_[q], to_f32<T>(dob[(long)q * p.do_ss + j]), c);
+        }
+        dkrow[j] = from_f32<T>(a);
+        dvrow[j] = from_f32<T>(c);
+    }
+}
+
+// ================================================================== decode: one query row vs. the K/V cache
+// cache [B][H][2][smax][HD]; thread (kk, part) streams 16-B chunks, fully coalesced.
+template <typename T, int HD>
+__global__ void attn_decode_kernel(const T* q, const T* cache, T* o, int H, int smax, int len) {
+    constexpr int E = 16 / sizeof(T);            // elements per 16-B chunk
+    constexpr int PARTS = HD / E;
+    constexpr int NTH = (HD == 96) ? 192 : 256;
+    constexpr int KPP = NTH / PARTS;             // keys per pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);          // [HD]
+    float* sc = qs + HD;                                 // [len]
+    float* pd = sc + ((len + 3) & ~3);                   // [len*PARTS] then reused as [KPP][HD]
+    __shared__ float red[16];
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int part = tid % PARTS, kk = tid / PARTS;
+    const T* Kc = cache + ((long)bh * 2 + 0) * smax * HD;
+    const T* Vc = cache + ((long)bh * 2 + 1) * smax * HD;
+    for (int j = tid; j < HD; j += NTH) qs[j] = to_f32<T>(q[(long)bh * HD + j]);
+    __syncthreads();
+    for (int key = kk; key < len; key += KPP) {
+        const T* src = Kc + (long)key * HD + part * E;
+        float a = 0.f;
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a = fmaf(qs[part * E + e], (float)v[e], a);
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a = fmaf(qs[part * E + e], v[e], a);
+        }
+        pd[key * PARTS + part] = a;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = tid; key < len; key += NTH) {
+        float s = 0.f;
+        for (int pp = 0; pp < PARTS; ++pp) s += pd[key * PARTS + pp];
+        sc[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int key = tid; key < len; key += NTH) { const float e = expf(sc[key] - mx); sc[key] = e; sum += e; }
+    sum = block_sum(sum, red);
+    __syncthreads();
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int key = kk; key < len; key += KPP) {
+        const T* src = Vc + (long)key * HD + part * E;
+        const float w = sc[key];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(w, (float)v[e], acc[e]);
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+        }
+    }
+    __syncthreads();   // everyone is done reading pd as scores
+#pragma unroll
+    for (int e = 0; e < E; ++e) pd[kk * HD + part * E + e] = acc[e];
+    __syncthreads();
+    const float inv = 1.f / sum;
+    for (int j = tid; j < HD; j += NTH) {
+        float a = 0.f;
+        for (int k2 = 0; k2 < KPP; ++k2) a += pd[k2 * HD + j];
+        o[(long)bh * HD + j] = from_f32<T>(a * inv);
+    }
+}
+
+// ------------------------------------------------------------------ host helpers
+int fill_args(const capdec_attn_desc* d, AttnArgs& a) {
+    CAPDEC_CHECK(d && d->q && d->k && d->v, "attn: null pointer");
+    CAPDEC_CHECK(d->dtype == CAPDEC_BF16 || d->dtype == CAPDEC_F32, "attn: bad dtype");
+    CAPDEC_CHECK(d->B > 0 && d->H > 0 && d->S > 0 && d->hd > 0, "attn: bad shape");
+    CAPDEC_CHECK(d->q_start >= 0 && d->nq >= 0 && d->q_start + d->nq <= d->S, "attn: query range [%d,%d) outside sequence %d", d->q_start, d->q_start + d->nq, d->S);
+    CAPDEC_CHECK((long)d->B * d->H * d->S * d->S < (1L << 32) || d->drop.p <= 0.f, "attn: dropout index space exceeds 2^32");
+    memset(&a, 0, sizeof(a));
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o;
+    a.q_bs = d->q_bs; a.q_hs = d->q_hs; a.q_ss = d->q_ss;
+    a.k_bs = d->k_bs; a.k_hs = d->k_hs; a.k_ss = d->k_ss;
+    a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_ss = d->v_ss;
+    a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_ss = d->o_ss;
+    a.B = d->B; a.H = d->H; a.S = d->S; a.hd = d->hd; a.q_start = d->q_start; a.nq = d->nq;
+    a.mask_mode = d->mask_mode;
+    a.open_cols = d->mask_mode == CAPDEC_MASK_REFERENCE ? 16 * 768 : (d->mask_mode == CAPDEC_MASK_PREFIX_CAUSAL ? d->prefix_len : 0);
+    a.drop_thr = d->drop.p > 0.f ? dropout_threshold(d->drop.p) : 0u;
+    a.drop_k0 = d->drop.key0; a.drop_k1 = d->drop.key1;
+    a.drop_scale = d->drop.p > 0.f ? 1.f / (1.f - d->drop.p) : 1.f;
+    a.lse = d->lse;
+    return CAPDEC_OK;
+}
+
+bool strides_ok8(long a, long b, long c) { return (a % 8) == 0 && (b % 8) == 0 && (c % 8) == 0; }
+
+template <typename K>
+void set_lds(K kernel, int bytes) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+#define HD_DISPATCH(HDV, ...)                                      \
+    switch (HDV) {                                                 \
+        case 32: { constexpr int HD = 32; __VA_ARGS__; } break;    \
+        case 64: { constexpr int HD = 64; __VA_ARGS__; } break;    \
+        case 96: { constexpr int HD = 96; __VA_ARGS__; } break;    \
+        case 128: { constexpr int HD = 128; __VA_ARGS__; } break;  \
+        default: capdec_set_error("attn: head dim %d not supported (32/64/96/128)", HDV); return CAPDEC_ERR_INVALID; \
+    }
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
+    AttnArgs a;
+    int rc = fill_args(d, a);
+    if (rc) return rc;
+    CAPDEC_CHECK(d->o, "attn_fwd: null output");
+    if (d->nq == 0) return CAPDEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CAPDEC_BF16) {
+        CAPDEC_CHECK(strides_ok8(a.q_bs, a.q_hs, a.q_ss) && strides_ok8(a.k_bs, a.k_hs, a.k_ss) && strides_ok8(a.v_bs, a.v_hs, a.v_ss) &&
+                     (a.o_bs % 4) == 0 && (a.o_hs % 4) == 0 && (a.o_ss % 4) == 0 && aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.o),
+                     "attn_fwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
+        const int SP = (a.S + 63) & ~63;
+        const int lds = 2 * SP * (a.hd * 2 + 16);
+        CAPDEC_CHECK(lds <= 160 * 1024, "attn_fwd(bf16): sequence %d too long for the LDS-resident K/V design (hd=%d)", a.S, a.hd);
+        dim3 grid(a.B * a.H, (a.nq + 63) / 64), block(256);
+        HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD>, lds); hipLaunchKernelGGL(attn_fwd_mfma<HD>, grid, block, lds, st, a));
+    } else {
+        const int lds = (a.hd + a.S) * 4;
+        dim3 grid(a.B * a.H, a.nq), block(64);
+        hipLaunchKernelGGL(attn_fwd_simple<float>, grid, block, lds, st, a);
+    }
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
+    CAPDEC_CHECK(d, "attn_bwd: null descriptor");
+    AttnArgs a;
+    int rc = fill_args(&d->fwd, a);
+    if (rc) return rc;
+    CAPDEC_CHECK(d->fwd.o && d->fwd.lse && d->dout && d->dq && d->dk && d->dv && d->delta, "attn_bwd: null pointer");
+    a.dout = d->dout; a.do_bs = d->do_bs; a.do_hs = d->do_hs; a.do_ss = d->do_ss;
+    a.dq = d->dq; a.dq_bs = d->dq_bs; a.dq_hs = d->dq_hs; a.dq_ss = d->dq_ss;
+    a.dk = d->dk; a.dk_bs = d->dk_bs; a.dk_hs = d->dk_hs; a.dk_ss = d->dk_ss;
+    a.dv = d->dv; a.dv_bs = d->dv_bs; a.dv_hs = d->dv_hs; a.dv_ss = d->dv_ss;
+    a.dq_scale = d->dq_scale; a.delta = d->delta;
+    hipStream_t st = (hipStream_t)stream;
+    const long nrow = (long)a.B * a.H * a.nq;
+    if (a.nq > 0) {
+        if (d->fwd.dtype == CAPDEC_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, a);
+    }
+    if (d->fwd.dtype == CAPDEC_BF16) {
+        CAPDEC_CHECK(strides_ok8(a.q_bs, a.q_hs, a.q_ss) && strides_ok8(a.k_bs, a.k_hs, a.k_ss) && strides_ok8(a.v_bs, a.v_hs, a.v_ss) &&
+                     strides_ok8(a.do_bs, a.do_hs, a.do_ss) && (a.dq_bs % 4) == 0 && (a.dq_hs % 4) == 0 && (a.dq_ss % 4) == 0 &&
+                     (a.dk_bs % 4) == 0 && (a.dk_hs % 4) == 0 && (a.dk_ss % 4) == 0 && (a.dv_bs % 4) == 0 && (a.dv_hs % 4) == 0 && (a.dv_ss % 4) == 0 &&
+                     aligned16(a.dout) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv),
+                     "attn_bwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
+        const int SP = (a.S + 63) & ~63;
+        const int lds_q = 2 * SP * (a.hd * 2 + 16);
+        const int NQP = (a.nq + 31) & ~31;
+        const int lds_k = 2 * NQP * (a.hd * 2 + 16) + 2 * NQP * 4;
+        CAPDEC_CHECK(lds_q <= 160 * 1024 && lds_k <= 160 * 1024, "attn_bwd(bf16): sequence %d too long for the LDS-resident design (hd=%d)", a.S, a.hd);
+        dim3 block(256);
+        if (a.nq > 0) {
+            dim3 gq(a.B * a.H, (a.nq + 63) / 64);
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD>, lds_q); hipLaunchKernelGGL(attn_bwd_dq_mfma<HD>, gq, block, lds_q, st, a));
+        }
+        dim3 gk(a.B * a.H, (a.S + 63) / 64);
+        HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD>, lds_k); hipLaunchKernelGGL(attn_bwd_dkv_mfma<HD>, gk, block, lds_k, st, a));
+    } else {
+        if (a.nq > 0) {
+            const int lds_q = (2 * a.hd + a.S) * 4;
+            hipLaunchKernelGGL(attn_bwd_dq_simple<float>, dim3(a.B * a.H, a.nq), dim3(64), lds_q, st, a);
+        }
+        const int lds_k = (2 * a.hd + 2 * a.S) * 4;
+        hipLaunchKernelGGL(attn_bwd_dkv_simple<float>, dim3(a.B * a.H, a.S), dim3(64), lds_k, st, a);
+    }
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_attn_decode(const void* q, const void* kv_cache, void* o, int dtype,
+                                  int B, int H, int hd, int smax, int len, void* stream) {
+    CAPDEC_CHECK(q && kv_cache && o, "attn_decode: null pointer");
+    CAPDEC_CHECK(B > 0 && H > 0 && len > 0 && len <= smax, "attn_decode: bad shape (len=%d, smax=%d)", len, smax);
+    CAPDEC_CHECK(dtype == CAPDEC_BF16 || dtype == CAPDEC_F32, "attn_decode: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int nth = hd == 96 ? 192 : 256;
+    const int E = dtype == CAPDEC_BF16 ? 8 : 4;
+    const int parts = hd / E, kpp = nth / parts;
+    const int pd_floats = len * parts > kpp * hd ? len * parts : kpp * hd;
+    const int lds = (hd + ((len + 3) & ~3) + pd_floats) * 4;
+    CAPDEC_CHECK(lds <= 64 * 1024, "attn_decode: cache length %d too long", len);
+    dim3 grid(B * H), block(nth);
+    if (dtype == CAPDEC_BF16) {
+        HD_DISPATCH(hd, hipLaunchKernelGGL((attn_decode_kernel<bf16_t, HD>), grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)kv_cache, (bf16_t*)o, H, smax, len));
+    } else {
+        HD_DISPATCH(hd, hipLaunchKernelGGL((attn_decode_kernel<float, HD>), grid, block, lds, st, (const float*)q, (const float*)kv_cache, (float*)o, H, smax, len));
+    }
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}

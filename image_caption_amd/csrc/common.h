@@ -1,0 +1,116 @@
+// Shared device/host helpers for libcapdec (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/capdec.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---------------------------------------------------------------- errors
+void capdec_set_error(const char* fmt, ...);
+
+#define CAPDEC_CHECK(cond, ...)                   \
+    do {                                          \
+        if (!(cond)) {                            \
+            capdec_set_error(__VA_ARGS__);        \
+            return CAPDEC_ERR_INVALID;            \
+        }                                         \
+    } while (0)
+
+#define CAPDEC_LAUNCH_CHECK()                                             \
+    do {                                                                  \
+        hipError_t e__ = hipGetLastError();                               \
+        if (e__ != hipSuccess) {                                          \
+            capdec_set_error("launch failed: %s", hipGetErrorString(e__)); \
+            return CAPDEC_ERR_LAUNCH;                                     \
+        }                                                                 \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------- dtype access
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float load_as_f32(const void* p, long i, int dtype) {
+    return dtype == CAPDEC_BF16 ? (float)((const bf16_t*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void store_from_f32(void* p, long i, int dtype, float v) {
+    if (dtype == CAPDEC_BF16) ((bf16_t*)p)[i] = (bf16_t)v; else ((float*)p)[i] = v;
+}
+
+// ---------------------------------------------------------------- dropout RNG
+// Counter-based: keep(idx) depends only on (key0, key1, idx), so the backward
+// pass regenerates the forward's mask from the same keys with no stored mask.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t dropout_bits(uint32_t key0, uint32_t key1, uint32_t idx) {
+    return mix32(mix32(idx * 0x9E3779B1U + key0) ^ key1);
+}
+// threshold = floor(p * 2^32); keep when bits >= threshold
+__device__ __forceinline__ bool dropout_keep(uint32_t key0, uint32_t key1, uint32_t idx, uint32_t thr) {
+    return dropout_bits(key0, key1, idx) >= thr;
+}
+static inline uint32_t dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0) return 0;
+    if (t >= 4294967295.0) return 4294967295U;
+    return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block reduce for blockDim.x <= 1024 (multiple of 64); scratch holds >= 16 floats
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}

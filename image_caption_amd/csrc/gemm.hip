@@ -1,0 +1,726 @@
+// GEMM with fused epilogues for the captioning decoder (gfx950).
+//
+//   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// bf16 operands: 128x128x64 tiles, 4 waves (2x2), each wave 4x4 MFMA 16x16x32
+// tiles with f32 accumulators.  Operand tiles are fetched with bounds-checked
+// buffer loads (out-of-range reads return 0, which implements every M/N/K tail),
+// staged in LDS with an XOR swizzle, double buffered.  An operand stored
+// reduction-major ([K][rows], the dgrad / wgrad cases) is read back with the
+// hardware transposing LDS read (ds_read_b64_tr_b16), so no transposed copies of
+// weights or activations are ever made.
+// f32 operands: exact-f32 FMA main loop (validation mode), same epilogues.
+//
+// Every epilogue works on the accumulator tile after it has been staged through
+// LDS, row-major, so global stores / residual reads are 8-16 B per lane and
+// contiguous across 16 lanes.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int CS_LD = 68;                        // floats per row of a wave's 64x64 staging tile
+constexpr int CS_WAVE_BYTES = 64 * CS_LD * 4;    // 17408
+constexpr int LDS_BYTES = 4 * CS_WAVE_BYTES;     // 69632 >= 2 stages * (16 KiB A + 16 KiB B)
+constexpr int STAGE_BYTES = 32768;
+constexpr int TILE_BYTES = 16384;
+
+enum { EPI_STD = 0, EPI_CE_FWD = 1, EPI_CE_BWD = 2 };
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    int out_dtype;
+    const float* bias;
+    float col_scale; int col_scale_n;
+    int act;
+    float drop_scale; uint32_t drop_thr, drop_k0, drop_k1;      // thr 0 = off
+    const float* residual; long ldr;
+    int accumulate;
+    const void* gate; long ldg; int gate_mode; int gate_dtype;
+    float gate_scale; uint32_t gate_thr, gate_k0, gate_k1;
+    void* aux_out; long ldaux;
+    float* colsum;
+    void* kv_cache; int kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
+    // cross-entropy epilogues
+    const int64_t* labels; int ce_B, ce_L; int ce_col0;
+    float* pmax; float* psum; float* psec; int* parg; float* zlabel; int np;
+    const float* lse; float gscale; int store_cols;
+};
+
+// ------------------------------------------------------------------ tile order
+// Blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+// run of logical tile ids (bijective for any grid size), and walk those ids in
+// groups of 8 M-tiles x all N-tiles so that co-resident tiles share operand panels
+// in that XCD's L2.
+__device__ __forceinline__ void map_tile(int tm, int tn, int& tile_m, int& tile_n) {
+    const int nwg = tm * tn;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tn;
+    const int grp = logical / per_group;
+    const int first_m = grp * GROUP;
+    const int gsz = min(tm - first_m, GROUP);
+    const int in = logical - grp * per_group;
+    tile_m = first_m + in % gsz;
+    tile_n = in / gsz;
+}
+
+// ------------------------------------------------------------------ LDS images
+// Row-major operand tile [128 rows][64 k] bf16, 128-B rows; the 16-B chunk index is
+// XORed with (row & 7) so that the 16 rows one ds_read_b128 group touches fall on
+// 16 different slots of the 256-B bank row.
+__device__ __forceinline__ int lds_off_rowmajor(int row, int kc) { return row * 128 + ((kc ^ (row & 7)) << 4); }
+// Reduction-major operand tile [64 k][128 cols] bf16, 256-B rows; 32-B column blocks
+// are XORed with a 3-bit function of k that is distinct over the 8 k-rows one
+// transposing read touches per half-wave.
+__device__ __forceinline__ int kswz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+__device__ __forceinline__ int lds_off_kmajor(int krow, int chunk16) { return krow * 256 + ((chunk16 ^ (kswz(krow) << 1)) << 4); }
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int ks, int lane) {
+    if constexpr (!TR) {
+        const int row = rb + (lane & 15);
+        const int kc = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(tile + lds_off_rowmajor(row, kc));
+    } else {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int krow = ks * 32 + 8 * g + q;
+        const int col = rb + 4 * pp;
+        const int off = lds_off_kmajor(krow, col >> 3) + ((col & 7) << 1);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + off));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + off + 4 * 256));
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+// ------------------------------------------------------------------ operand fetch
+struct OperandView {
+    const bf16_t* base;   // first element of this block's panel
+    long remaining;       // elements addressable from base
+    long ld;
+    int rows_left;        // valid rows (non-reduction index) from the panel start
+};
+
+template <bool TR>
+__device__ __forceinline__ void fetch_tile(const OperandView& v, int k0, int K, int tid, u32x4 (&r)[4]) {
+    // base pointer advanced to this k-tile (wave-uniform), 32-bit offsets inside it
+    const long adv = TR ? (long)k0 * v.ld : (long)k0;
+    long rem = (v.remaining - adv) * 2;
+    rem = rem < 0 ? 0 : (rem > 0xFFFFFFF0L ? 0xFFFFFFF0L : rem);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)(unsigned)rem, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTHREADS * i;
+        unsigned off;
+        if constexpr (!TR) {
+            const int row = c >> 3, kc = c & 7;
+            off = (unsigned)(((long)row * v.ld + kc * 8) * 2);
+            if (k0 + kc * 8 >= K) off = 0xFFFFFFFFu;
+        } else {
+            const int krow = c >> 4, rc = c & 15;
+            off = (unsigned)(((long)krow * v.ld + rc * 8) * 2);
+            if (rc * 8 >= v.rows_left || k0 + krow >= K) off = 0xFFFFFFFFu;
+        }
+        r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        if constexpr (!TR) {
+            // a chunk that straddles K: zero the elements at k >= K (they belong to the row's padding)
+            const int kk = K - (k0 + (c & 7) * 8);
+            if (kk > 0 && kk < 8) {
+#pragma unroll
+                for (int dw = 0; dw < 4; ++dw) {
+                    if (2 * dw >= kk) r[i][dw] = 0u;
+                    else if (2 * dw + 1 >= kk) r[i][dw] &= 0xFFFFu;
+                }
+            }
+        }
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void stash_tile(char* tile, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTHREADS * i;
+        int off;
+        if constexpr (!TR) off = lds_off_rowmajor(c >> 3, c & 7);
+        else off = lds_off_kmajor(c >> 4, c & 15);
+        *reinterpret_cast<u32x4*>(tile + off) = r[i];
+    }
+}
+
+// ------------------------------------------------------------------ epilogues
+// All take the wave's 64x64 f32 tile in LDS (row stride CS_LD) and the global
+// coordinates (mw, nw) of its corner.
+
+__device__ __forceinline__ float epi_value(const GemmArgs& p, float v, long m, int n) {
+    if (p.bias) v += p.bias[n];
+    if (n < p.col_scale_n) v *= p.col_scale;
+    if (p.aux_out) store_from_f32(p.aux_out, m * p.ldaux + n, p.out_dtype, v);
+    if (p.act == CAPDEC_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == CAPDEC_ACT_GELU) v = gelu_f(v);
+    if (p.gate_mode == CAPDEC_GATE_RELU_OUT) {
+        const float g = load_as_f32(p.gate, m * p.ldg + n, p.gate_dtype);
+        v = (g != 0.f) ? v * p.gate_scale : 0.f;
+    } else if (p.gate_mode == CAPDEC_GATE_GELU_PRE) {
+        const float z = load_as_f32(p.gate, m * p.ldg + n, p.gate_dtype);
+        float f = gelu_grad_f(z);
+        if (p.gate_thr) f = dropout_keep(p.gate_k0, p.gate_k1, (uint32_t)(m * p.N + n), p.gate_thr) ? f * p.gate_scale : 0.f;
+        v *= f;
+    }
+    if (p.drop_thr) v = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)(m * p.N + n), p.drop_thr) ? v * p.drop_scale : 0.f;
+    if (p.residual) v += p.residual[m * p.ldr + n];
+    return v;
+}
+
+__device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
+    const int c4 = (lane & 15) * 4;
+    const int n = nw + c4;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec_ok = (n + 3 < p.N) && ((p.ldc & 3) == 0) && !p.kv_cache;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const long m = (long)mw + row;
+        if (m >= p.M || n >= p.N) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = 0.f;
+            if (n + e < p.N) {
+                v[e] = epi_value(p, a[e], m, n + e);
+                if (p.accumulate) v[e] += ((const float*)p.C)[m * p.ldc + n + e];
+                csum[e] += v[e];
+            }
+        }
+        if (p.kv_cache && n >= p.kv_d) {
+            // K/V columns: cache[b][h][k|v][kv_s0 + s][j]
+            const int nn = n - p.kv_d;
+            const int which = nn / p.kv_d, rem = nn - which * p.kv_d;
+            const int hh = rem / p.kv_hd, j = rem - hh * p.kv_hd;
+            const long s = m / p.kv_B, b = m - s * p.kv_B;
+            const long dst = ((((b * p.kv_H + hh) * 2 + which) * p.kv_smax) + p.kv_s0 + s) * p.kv_hd + j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) store_from_f32(p.kv_cache, dst + e, p.out_dtype, v[e]);
+        } else if (vec_ok) {
+            if (p.out_dtype == CAPDEC_BF16) {
+                bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+                *reinterpret_cast<bf16x4*>((bf16_t*)p.C + m * p.ldc + n) = o;
+            } else {
+                f32x4 o = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>((float*)p.C + m * p.ldc + n) = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) store_from_f32(p.C, m * p.ldc + n + e, p.out_dtype, v[e]);
+        }
+    }
+    if (p.colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = csum[e];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16 && n + e < p.N) atomicAdd(p.colsum + n + e, s);
+        }
+    }
+}
+
+struct Top2 { float m1; int a1; float m2; };
+__device__ __forceinline__ void top2_push(Top2& t, float v, int idx) {
+    if (v > t.m1 || (v == t.m1 && idx < t.a1)) { t.m2 = t.m1; t.m1 = v; t.a1 = idx; }
+    else if (v > t.m2) t.m2 = v;
+}
+__device__ __forceinline__ void top2_merge(Top2& t, float m1, int a1, float m2) {
+    if (m1 > t.m1 || (m1 == t.m1 && a1 < t.a1)) { t.m2 = fmaxf(t.m1, m2); t.m1 = m1; t.a1 = a1; }
+    else t.m2 = fmaxf(t.m2, m1);
+}
+
+// per (row, 64-column slot): max, second max, argmax, sum exp(z - max); the label's logit
+__device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, const float* cs, int mw, int nw, int slot, int lane) {
+    const int c4 = (lane & 15) * 4;
+    const int n = nw + c4;
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const long m = (long)mw + row;
+        const bool live = m < p.M;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
+        long label = -1;
+        if (live && p.labels) {
+            const long l = m / p.ce_B, b = m - l * p.ce_B;
+            label = p.labels[b * p.ce_L + l];
+        }
+        float z[4];
+        Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            z[e] = (n + e < p.N) ? a[e] + (p.bias ? p.bias[n + e] : 0.f) : -INFINITY;
+            if (n + e < p.N) top2_push(t, z[e], n + e);
+            if (live && (long)(n + e) == label) p.zlabel[m] = z[e];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const float om1 = __shfl_xor(t.m1, o, 64), om2 = __shfl_xor(t.m2, o, 64);
+            const int oa1 = __shfl_xor(t.a1, o, 64);
+            top2_merge(t, om1, oa1, om2);
+        }
+        float s = 0.f;
+        if (t.m1 > -INFINITY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += (n + e < p.N) ? __expf(z[e] - t.m1) : 0.f;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (live && (lane & 15) == 0) {
+            const long o = m * p.np + slot;
+            p.pmax[o] = t.m1; p.psec[o] = t.m2; p.parg[o] = t.a1; p.psum[o] = s;
+        }
+    }
+}
+
+// dl = (softmax - onehot) * gscale for one vocabulary slab
+__device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
+    const int c4 = (lane & 15) * 4;
+    const int n = nw + c4;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const long m = (long)mw + row;
+        if (m >= p.M || n >= p.store_cols) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
+        const long l = m / p.ce_B, b = m - l * p.ce_B;
+        const long label = p.labels[b * p.ce_L + l];
+        const float lse = p.lse[m];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = 0.f;
+            if (n + e < p.N) {
+                const float z = a[e] + (p.bias ? p.bias[n + e] : 0.f);
+                v[e] = (__expf(z - lse) - ((long)(n + e + p.ce_col0) == label ? 1.f : 0.f)) * p.gscale;
+                csum[e] += v[e];
+            }
+        }
+        if (p.out_dtype == CAPDEC_BF16) {
+            bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+            *reinterpret_cast<bf16x4*>((bf16_t*)p.C + m * p.ldc + n) = o;
+        } else {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>((float*)p.C + m * p.ldc + n) = o;
+        }
+    }
+    if (p.colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = csum[e];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16 && n + e < p.N) atomicAdd(p.colsum + n + e, s);
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void run_epilogue(const GemmArgs& p, const char* smem, int m0, int n0, int tile_n, int wave, int lane) {
+    const int wr = wave >> 1, wc = wave & 1;
+    const float* cs = reinterpret_cast<const float*>(smem + wave * CS_WAVE_BYTES);
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    if constexpr (EPI == EPI_STD) epilogue_std(p, cs, mw, nw, lane);
+    else if constexpr (EPI == EPI_CE_FWD) epilogue_ce_fwd(p, cs, mw, nw, tile_n * 2 + wc, lane);
+    else epilogue_ce_bwd(p, cs, mw, nw, lane);
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel
+template <bool A_TR, bool B_TR, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    map_tile(tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    OperandView va, vb;
+    if (A_TR) { va.base = (const bf16_t*)p.A + m0; va.remaining = (long)p.K * p.lda - m0; }
+    else      { va.base = (const bf16_t*)p.A + (long)m0 * p.lda; va.remaining = (long)(p.M - m0) * p.lda; }
+    va.ld = p.lda; va.rows_left = p.M - m0;
+    if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
+    else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
+    vb.ld = p.ldb; vb.rows_left = p.N - n0;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    u32x4 ra[4], rb[4];
+    fetch_tile<A_TR>(va, 0, p.K, tid, ra);
+    fetch_tile<B_TR>(vb, 0, p.K, tid, rb);
+    stash_tile<A_TR>(smem, tid, ra);
+    stash_tile<B_TR>(smem + TILE_BYTES, tid, rb);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = smem + (kt & 1) * STAGE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            fetch_tile<A_TR>(va, (kt + 1) * BK, p.K, tid, ra);
+            fetch_tile<B_TR>(vb, (kt + 1) * BK, p.K, tid, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<A_TR>(sA, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_TR>(sB, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            stash_tile<A_TR>(dA, tid, ra);
+            stash_tile<B_TR>(dA + TILE_BYTES, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // stage accumulators: lane holds C[row = 4*(lane>>4) + r][col = lane & 15] of each 16x16 tile
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
+    __builtin_amdgcn_wave_barrier();
+    run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
+}
+
+// ------------------------------------------------------------------ exact-f32 kernel (validation mode)
+template <typename T, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FK = 16, FLD = 132;
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + FK * FLD;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    map_tile(tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ty = tid >> 4, tx = tid & 15;
+    const T* A = (const T*)p.A;
+    const T* B = (const T*)p.B;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += FK) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + NTHREADS * i;
+            int mm, kk;
+            if (p.a_kmajor) { kk = e >> 7; mm = e & 127; } else { mm = e >> 4; kk = e & 15; }
+            float v = 0.f;
+            if (m0 + mm < p.M && k0 + kk < p.K)
+                v = to_f32<T>(p.a_kmajor ? A[(long)(k0 + kk) * p.lda + m0 + mm] : A[(long)(m0 + mm) * p.lda + k0 + kk]);
+            As[kk * FLD + mm] = v;
+            int nn;
+            if (p.b_kmajor) { kk = e >> 7; nn = e & 127; } else { nn = e >> 4; kk = e & 15; }
+            v = 0.f;
+            if (n0 + nn < p.N && k0 + kk < p.K)
+                v = to_f32<T>(p.b_kmajor ? B[(long)(k0 + kk) * p.ldb + n0 + nn] : B[(long)(n0 + nn) * p.ldb + k0 + kk]);
+            Bs[kk * FLD + nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < FK; ++kk) {
+            float a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = As[kk * FLD + ty * 8 + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = Bs[kk * FLD + tx * 8 + j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int mm = ty * 8 + i, nn = tx * 8 + j;
+            const int w = (mm >> 6) * 2 + (nn >> 6);
+            reinterpret_cast<float*>(smem + w * CS_WAVE_BYTES)[(mm & 63) * CS_LD + (nn & 63)] = acc[i][j];
+        }
+    __syncthreads();
+    run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
+}
+
+// ------------------------------------------------------------------ launch
+template <int EPI>
+int launch_gemm(const GemmArgs& a, int in_dtype, hipStream_t st) {
+    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    const long nwg = (long)tm * tn;
+    if (nwg <= 0) return CAPDEC_OK;
+    CAPDEC_CHECK(nwg < (1L << 31), "gemm: too many tiles");
+    dim3 grid((unsigned)nwg), block(NTHREADS);
+    if (in_dtype == CAPDEC_BF16) {
+        CAPDEC_CHECK((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm(bf16): lda/ldb must be multiples of 8 (got %ld, %ld)", a.lda, a.ldb);
+        CAPDEC_CHECK(aligned16(a.A) && aligned16(a.B), "gemm(bf16): A/B must be 16-byte aligned");
+#define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
+    do {                                                                                               \
+        static bool attr_set = false;                                                                  \
+        if (!attr_set) {                                                                               \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                \
+            attr_set = true;                                                                           \
+        }                                                                                              \
+        hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);            \
+    } while (0)
+        if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
+        else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
+        else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
+        else CAPDEC_GEMM_CASE(true, true);
+#undef CAPDEC_GEMM_CASE
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<float, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_kernel<float, EPI>), grid, block, LDS_BYTES, st, a);
+    }
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+// ------------------------------------------------------------------ CE finalize kernels
+// one wave per row: fold the per-slot partials into lse / argmax / margin / row loss
+__global__ void ce_finalize_kernel(const float* pmax, const float* psum, const float* psec, const int* parg,
+                                   const float* zlabel, const int64_t* labels, int ce_B, int ce_L, long M, int np,
+                                   float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
+                                   float* rowloss, int32_t* rowcorrect) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+    for (int s = lane; s < np; s += 64) {
+        const long o = m * np + s;
+        top2_merge(t, pmax[o], parg[o], psec[o]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om1 = __shfl_xor(t.m1, o, 64), om2 = __shfl_xor(t.m2, o, 64);
+        const int oa1 = __shfl_xor(t.a1, o, 64);
+        top2_merge(t, om1, oa1, om2);
+    }
+    float s = 0.f;
+    for (int sl = lane; sl < np; sl += 64) {
+        const long o = m * np + sl;
+        const float pm = pmax[o];
+        if (pm > -INFINITY) s += psum[o] * __expf(pm - t.m1);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float lse = t.m1 + logf(s);
+        if (lse_out) lse_out[m] = lse;
+        if (argmax_out) argmax_out[m] = t.a1;
+        if (ids_out) ids_out[m] = t.a1;
+        if (margin_out) margin_out[m] = t.m1 - t.m2;
+        if (labels) {
+            const long l = m / ce_B, b = m - l * ce_B;
+            rowloss[m] = lse - zlabel[m];
+            rowcorrect[m] = ((long)t.a1 == labels[b * ce_L + l]) ? 1 : 0;
+        }
+    }
+}
+
+// fixed-order sum of the per-row losses (deterministic)
+__global__ void ce_reduce_kernel(const float* rowloss, const int32_t* rowcorrect, long M, float* loss_sum, int32_t* correct) {
+    __shared__ float sf[16];
+    __shared__ int si[16];
+    float a = 0.f;
+    int c = 0;
+    for (long i = threadIdx.x; i < M; i += blockDim.x) { a += rowloss[i]; c += rowcorrect[i]; }
+    a = wave_sum(a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) { sf[threadIdx.x >> 6] = a; si[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f; int rc = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { r += sf[i]; rc += si[i]; }
+        loss_sum[0] = r; correct[0] = rc;
+    }
+}
+
+uint32_t keyed_thr(const capdec_dropout& d) { return d.p > 0.f ? dropout_threshold(d.p) : 0u; }
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
+    CAPDEC_CHECK(d != nullptr, "gemm: null descriptor");
+    CAPDEC_CHECK(d->M >= 0 && d->N >= 0 && d->K >= 0, "gemm: negative dimension");
+    CAPDEC_CHECK(d->in_dtype == CAPDEC_BF16 || d->in_dtype == CAPDEC_F32, "gemm: bad in_dtype");
+    CAPDEC_CHECK(d->out_dtype == CAPDEC_BF16 || d->out_dtype == CAPDEC_F32, "gemm: bad out_dtype");
+    CAPDEC_CHECK(!d->accumulate || d->out_dtype == CAPDEC_F32, "gemm: accumulate needs f32 output");
+    CAPDEC_CHECK(d->A && d->B && d->C, "gemm: null operand");
+    CAPDEC_CHECK((long)d->M * d->N < (1L << 32) || (d->drop.p <= 0.f && d->gate_mode != CAPDEC_GATE_GELU_PRE),
+                 "gemm: dropout index space exceeds 2^32 elements");
+    if (d->M == 0 || d->N == 0) return CAPDEC_OK;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = d->A; a.B = d->B; a.C = d->C;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.a_kmajor = d->a_kmajor; a.b_kmajor = d->b_kmajor;
+    a.out_dtype = d->out_dtype;
+    a.bias = d->bias; a.col_scale = d->col_scale; a.col_scale_n = d->col_scale_n;
+    a.act = d->act;
+    a.drop_thr = keyed_thr(d->drop); a.drop_k0 = d->drop.key0; a.drop_k1 = d->drop.key1;
+    a.drop_scale = d->drop.p > 0.f ? 1.0f / (1.0f - d->drop.p) : 1.0f;
+    a.residual = d->residual; a.ldr = d->ldr;
+    a.accumulate = d->accumulate;
+    a.gate = d->gate; a.ldg = d->ldg; a.gate_mode = d->gate ? d->gate_mode : CAPDEC_GATE_NONE; a.gate_dtype = d->gate_dtype;
+    a.gate_thr = keyed_thr(d->gate_drop); a.gate_k0 = d->gate_drop.key0; a.gate_k1 = d->gate_drop.key1;
+    a.gate_scale = d->gate_drop.p > 0.f ? 1.0f / (1.0f - d->gate_drop.p) : 1.0f;
+    a.aux_out = d->aux_out; a.ldaux = d->ldaux;
+    a.colsum = d->colsum;
+    a.kv_cache = d->kv_cache; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
+    a.kv_smax = d->kv_smax; a.kv_s0 = d->kv_s0;
+    if (a.kv_cache) {
+        CAPDEC_CHECK(a.kv_d > 0 && a.kv_B > 0 && a.kv_H > 0 && a.kv_hd > 0 && a.kv_H * a.kv_hd == a.kv_d && (a.kv_hd % 4) == 0,
+                     "gemm: inconsistent kv scatter geometry");
+        CAPDEC_CHECK(a.N == 3 * a.kv_d && (a.M % a.kv_B) == 0 && a.kv_s0 + a.M / a.kv_B <= a.kv_smax,
+                     "gemm: kv scatter out of range (N=%d, M=%d, s0=%d, smax=%d)", a.N, a.M, a.kv_s0, a.kv_smax);
+    }
+    return launch_gemm<EPI_STD>(a, d->in_dtype, (hipStream_t)stream);
+}
+
+extern "C" long capdec_logits_ce_workspace(long M, int V) {
+    const long np = 2L * ((V + BN - 1) / BN);
+    return (M * np * 4 + M * 3) * 4 + 256;
+}
+
+namespace {
+struct CeWs { float* pmax; float* psum; float* psec; int* parg; float* zlabel; float* rowloss; int32_t* rowcorrect; int np; };
+bool carve_ce_ws(void* ws, long bytes, long M, int V, CeWs& o) {
+    if (!ws || bytes < capdec_logits_ce_workspace(M, V)) return false;
+    o.np = 2 * ((V + BN - 1) / BN);
+    float* f = (float*)ws;
+    const long n = M * o.np;
+    o.pmax = f; o.psum = f + n; o.psec = f + 2 * n; o.parg = (int*)(f + 3 * n);
+    o.zlabel = f + 4 * n; o.rowloss = o.zlabel + M; o.rowcorrect = (int32_t*)(o.rowloss + M);
+    return true;
+}
+void fill_head_args(GemmArgs& a, const void* h, const void* W, const float* bias, long M, int V, int d, long ldh, long ldw) {
+    memset(&a, 0, sizeof(a));
+    a.A = h; a.B = W; a.M = (int)M; a.N = V; a.K = d; a.lda = ldh; a.ldb = ldw;
+    a.bias = bias;
+}
+}  // namespace
+
+extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
+                                    long M, int V, int d, long ldh, long ldw,
+                                    const int64_t* labels, int B, int L,
+                                    float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                                    void* workspace, long workspace_bytes, void* stream) {
+    CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct, "logits_ce_fwd: null pointer");
+    CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd: M (%ld) must equal B*L", M);
+    CeWs ws;
+    if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {
+        capdec_set_error("logits_ce_fwd: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_workspace(M, V));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    GemmArgs a;
+    fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
+    a.C = workspace;  // unused by this epilogue
+    a.labels = labels; a.ce_B = B; a.ce_L = L;
+    a.pmax = ws.pmax; a.psum = ws.psum; a.psec = ws.psec; a.parg = ws.parg; a.zlabel = ws.zlabel; a.np = ws.np;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
+    if (rc) return rc;
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(64 * rows_per_block), 0, st,
+                       ws.pmax, ws.psum, ws.psec, ws.parg, ws.zlabel, labels, B, L, M, ws.np,
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
+                                    long M, int V, int d, long ldh, long ldw,
+                                    int64_t* out_ids, float* margin,
+                                    void* workspace, long workspace_bytes, void* stream) {
+    CAPDEC_CHECK(h && W && out_ids, "logits_argmax: null pointer");
+    CAPDEC_CHECK(M < (1L << 31), "logits_argmax: M too large");
+    CeWs ws;
+    if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {
+        capdec_set_error("logits_argmax: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_workspace(M, V));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    GemmArgs a;
+    fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
+    a.C = workspace;
+    a.ce_B = 1; a.ce_L = 1;
+    a.pmax = ws.pmax; a.psum = ws.psum; a.psec = ws.psec; a.parg = ws.parg; a.zlabel = ws.zlabel; a.np = ws.np;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
+    if (rc) return rc;
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(64 * rows_per_block), 0, st,
+                       ws.pmax, ws.psum, ws.psec, ws.parg, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
+                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_logits_ce_bwd_slab(const void* h, const void* W, const float* bias, int dtype,
+                                         long M, int V, int d, long ldh, long ldw,
+                                         const int64_t* labels, int B, int L, const float* lse, float gscale,
+                                         int v0, int nv, void* dl, long ld_dl, float* dbias, void* stream) {
+    CAPDEC_CHECK(h && W && labels && lse && dl, "logits_ce_bwd_slab: null pointer");
+    CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_slab: M (%ld) must equal B*L", M);
+    CAPDEC_CHECK(v0 >= 0 && nv > 0 && v0 + nv <= V, "logits_ce_bwd_slab: slab [%d,%d) outside vocabulary %d", v0, v0 + nv, V);
+    CAPDEC_CHECK(ld_dl >= nv && (ld_dl % 4) == 0 && ld_dl <= (long)((nv + BN - 1) / BN) * BN,
+                 "logits_ce_bwd_slab: ld_dl (%ld) must be a multiple of 4 in [nv, roundup128(nv)]", ld_dl);
+    GemmArgs a;
+    const size_t esz = dtype == CAPDEC_BF16 ? 2 : 4;
+    fill_head_args(a, h, (const char*)W + (size_t)v0 * ldw * esz, bias ? bias + v0 : nullptr, M, nv, d, ldh, ldw);
+    a.C = dl; a.ldc = ld_dl; a.out_dtype = dtype; a.store_cols = (int)ld_dl;
+    a.labels = labels; a.ce_B = B; a.ce_L = L; a.ce_col0 = v0;
+    a.lse = lse; a.gscale = gscale;
+    a.colsum = dbias ? dbias + v0 : nullptr;
+    return launch_gemm<EPI_CE_BWD>(a, dtype, (hipStream_t)stream);
+}

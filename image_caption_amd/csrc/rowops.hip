@@ -1,0 +1,442 @@
+// HBM-bound row kernels: prefix join + LayerNorm, LayerNorm backward, casts,
+// dropout backward, bias-gradient column sums, token-embedding rows, Adam.
+// One wave per row for the LayerNorm family (a 768-wide f32 row is 3 KiB =
+// 3 x 16 B per lane), 16-B vector accesses everywhere.
+#include <stdarg.h>
+#include "common.h"
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[512] = "";
+void capdec_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* capdec_last_error(void) { return g_err; }
+extern "C" int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
+
+namespace {
+
+constexpr int LN_MAX_D = 2048;        // 8 x float4 per lane
+constexpr int LN_VEC = LN_MAX_D / 256;
+
+template <typename T>
+__device__ __forceinline__ f32x4 load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, f32x4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ------------------------------------------------------------------ LayerNorm forward (+ prefix join)
+// src row for output row r = s*B + b: patches, then the sos slot, then the caption
+template <typename TIN, typename TOUT, bool CONCAT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* sos, const TIN* cap, const float* xin,
+                                                      const float* pos, const float* gamma, const float* beta, float eps,
+                                                      long M, int B, int P, int L, int d,
+                                                      float* xout, TOUT* y, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    f32x4 v[LN_VEC];
+    float sum = 0.f;
+    long s = 0;
+    const TIN* src = nullptr;
+    if constexpr (CONCAT) {
+        s = r / B;
+        const long b = r - s * B;
+        src = s < P ? img + (b * P + s) * d : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
+    }
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        const int c = lane * 4 + i * 256;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            if constexpr (CONCAT) {
+                v[i] = load4<TIN>(src + c);
+                if (pos) v[i] += *reinterpret_cast<const f32x4*>(pos + s * d + c);
+                if (xout) *reinterpret_cast<f32x4*>(xout + r * d + c) = v[i];
+            } else {
+                v[i] = *reinterpret_cast<const f32x4*>(xin + r * d + c);
+            }
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    if (!y) return;
+    const float mu = wave_sum(sum) / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / d + eps);
+    if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
+            store4<TOUT>(y + r * d + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const float* gamma,
+                                                      const float* mean, const float* rstd, long M, int d,
+                                                      const float* dx_in, float* dx_out, float* partial) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 2 * 64 * 4];   // [wave][dgamma|dbeta][lane][4], one 1024-column slab per pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[LN_VEC], db[LN_VEC];
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) { dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0}; }
+    const long nwaves = (long)gridDim.x * 4;
+    for (long r = (long)blockIdx.x * 4 + wave; r < M; r += nwaves) {
+        const float mu = mean[r], rs = rstd[r];
+        f32x4 g[LN_VEC], xh[LN_VEC];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int c = lane * 4 + i * 256;
+            g[i] = f32x4{0, 0, 0, 0}; xh[i] = f32x4{0, 0, 0, 0};
+            if (c < d) {
+                const f32x4 dyv = load4<TDY>(dy + r * d + c);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * d + c);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    g[i][e] = dyv[e] * gm[e];
+                    c1 += g[i][e];
+                    c2 += g[i][e] * xh[i][e];
+                    dg[i][e] += dyv[e] * xh[i][e];
+                    db[i][e] += dyv[e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) / d;
+        c2 = wave_sum(c2) / d;
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+                if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + r * d + c);
+                *reinterpret_cast<f32x4*>(dx_out + r * d + c) = o;
+            }
+        }
+    }
+    // fold the 4 waves of this block, one 256-lane x 4 slab per pass, into partial[block][2][d]
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) {
+        if (i * 256 >= d) break;
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&red[((wave * 2 + 0) * 64 + lane) * 4]) = dg[i];
+        *reinterpret_cast<f32x4*>(&red[((wave * 2 + 1) * 64 + lane) * 4]) = db[i];
+        __syncthreads();
+        if (wave < 2) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
+                f32x4 s = f32x4{0, 0, 0, 0};
+                for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * 2 + wave) * 64 + lane) * 4]);
+                *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * 2 + wave) * d + c) = s;
+            }
+        }
+    }
+}
+
+__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
+    dgamma[c] = a; dbeta[c] = b;
+}
+
+int ln_bwd_blocks(long M) {
+    long nb = (M + 31) / 32;       // >= 8 rows per wave
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    return (int)nb;
+}
+
+// ------------------------------------------------------------------ element-wise
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* s, TD* d, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = from_f32<TD>(to_f32<TS>(s[i]));
+}
+
+__global__ void dropout_mask_kernel(uint32_t thr, uint32_t k0, uint32_t k1, long n, float* out) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (!thr || dropout_keep(k0, k1, (uint32_t)i, thr)) ? 1.f : 0.f;
+}
+
+// g = dx * keep/(1-p), column sums into colsum; thread owns 4 columns, block owns ROWS rows
+constexpr int CS_ROWS = 64;
+template <typename TG>
+__global__ __launch_bounds__(256) void dropout_bwd_cast_kernel(const float* dx, long M, int N, uint32_t thr, uint32_t k0, uint32_t k1,
+                                                                float scale, TG* g, float* colsum) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const long r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    const bool full = n + 3 < N && (N & 3) == 0;
+    for (long r = r0; r < r1; ++r) {
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (full) v = *reinterpret_cast<const f32x4*>(dx + r * N + n);
+        else for (int e = 0; e < 4 && n + e < N; ++e) v[e] = dx[r * N + n + e];
+        if (thr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dropout_keep(k0, k1, (uint32_t)(r * N + n + e), thr) ? v[e] * scale : 0.f;
+        }
+        if (full) store4<TG>(g + r * N + n, v);
+        else for (int e = 0; e < 4 && n + e < N; ++e) g[r * N + n + e] = from_f32<TG>(v[e]);
+        acc += v;
+    }
+    if (colsum)
+        for (int e = 0; e < 4 && n + e < N; ++e) atomicAdd(colsum + n + e, acc[e]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int N, long ldx, float* colsum) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const long r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    const bool full = n + 3 < N && (ldx & 3) == 0;
+    for (long r = r0; r < r1; ++r) {
+        if (full) acc += load4<T>(x + r * ldx + n);
+        else for (int e = 0; e < 4 && n + e < N; ++e) acc[e] += to_f32<T>(x[r * ldx + n + e]);
+    }
+    for (int e = 0; e < 4 && n + e < N; ++e) atomicAdd(colsum + n + e, acc[e]);
+}
+
+__global__ void embed_rows_kernel(const float* table, const int64_t* ids, long n, int d, const float* pos_row, float* out) {
+    const long i = blockIdx.x;
+    if (i >= n) return;
+    const float* src = table + ids[i] * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+        if (pos_row) v += *reinterpret_cast<const f32x4*>(pos_row + c);
+        *reinterpret_cast<f32x4*>(out + i * d + c) = v;
+    }
+}
+
+// torch.optim.Adam (coupled L2): g += wd*w; m,v EMA; w -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n,
+                                                    float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps,
+                                                    float wd, float gscale, bf16_t* wb) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 wv = *reinterpret_cast<f32x4*>(w + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
+            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * gscale + wd * wv[e];
+                mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+                vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+                wv[e] -= lr_over_bc1 * (mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps));
+            }
+            *reinterpret_cast<f32x4*>(w + i) = wv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+            if (wb) store4<bf16_t>(wb + i, wv);
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * gscale + wd * w[j];
+                m[j] = beta1 * m[j] + (1.f - beta1) * gg;
+                v[j] = beta2 * v[j] + (1.f - beta2) * gg * gg;
+                w[j] -= lr_over_bc1 * (m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + eps));
+                if (wb) wb[j] = (bf16_t)w[j];
+            }
+        }
+    }
+}
+
+__global__ void greedy_update_kernel(int64_t* ids, uint8_t* done, int64_t* out, int B, int L, int t, int64_t eos, int64_t pad) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t tok = ids[b];
+    if (done[b]) tok = pad;
+    ids[b] = tok;
+    out[(long)b * L + t] = tok;
+    if (tok == eos) done[b] = 1;
+}
+
+int grid_for(long n, int per_block, int cap = 4096) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" int capdec_dropout_mask(capdec_dropout d, long n, float* out, void* stream) {
+    CAPDEC_CHECK(out && n >= 0 && n < (1L << 32), "dropout_mask: bad arguments");
+    if (n == 0) return CAPDEC_OK;
+    const uint32_t thr = d.p > 0.f ? dropout_threshold(d.p) : 0u;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, thr, d.key0, d.key1, n, out);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+template <typename TIN, typename TOUT, bool CONCAT>
+static void launch_ln_fwd(const void* img, const void* sos, const void* cap, const float* xin, const float* pos,
+                          const float* gamma, const float* beta, float eps, long M, int B, int P, int L, int d,
+                          float* xout, void* y, float* mean, float* rstd, hipStream_t st) {
+    hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
+                       (const TIN*)img, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
+                       xout, (TOUT*)y, mean, rstd);
+}
+
+extern "C" int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int in_dtype,
+                                    const float* pos, const float* gamma, const float* beta, float eps,
+                                    int B, int P, int L, int d,
+                                    float* x, void* y, int y_dtype, float* mean, float* rstd, void* stream) {
+    CAPDEC_CHECK(img && sos && cap, "concat_ln_fwd: null input");
+    CAPDEC_CHECK(B > 0 && P >= 0 && L >= 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "concat_ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    CAPDEC_CHECK(x || y, "concat_ln_fwd: nothing to write");
+    CAPDEC_CHECK(!y || (gamma && beta), "concat_ln_fwd: LayerNorm output needs gamma/beta");
+    const long M = (long)(P + 1 + L) * B;
+    hipStream_t st = (hipStream_t)stream;
+    const bool ib = in_dtype == CAPDEC_BF16, ob = y_dtype == CAPDEC_BF16;
+    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
+    else if (ib) launch_ln_fwd<bf16_t, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
+    else if (ob) launch_ln_fwd<float, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int d,
+                             void* y, int y_dtype, float* mean, float* rstd, void* stream) {
+    CAPDEC_CHECK(x && y && gamma && beta, "ln_fwd: null pointer");
+    CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    if (M <= 0) return CAPDEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == CAPDEC_BF16) launch_ln_fwd<float, bf16_t, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, y, mean, rstd, st);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" long capdec_ln_bwd_workspace(long M, int d) { return (long)ln_bwd_blocks(M) * 2 * d * 4; }
+
+extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                             const float* mean, const float* rstd, long M, int d,
+                             const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+                             void* partial, void* stream) {
+    CAPDEC_CHECK(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && partial, "ln_bwd: null pointer");
+    CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_bwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    if (M <= 0) return CAPDEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_bwd_blocks(M);
+    if (dy_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {
+    CAPDEC_CHECK(src && dst && n >= 0, "cast: bad arguments");
+    if (n == 0) return CAPDEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(grid_for(n, 256, 8192)), b(256);
+    if (src_dtype == CAPDEC_F32 && dst_dtype == CAPDEC_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == CAPDEC_BF16 && dst_dtype == CAPDEC_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == CAPDEC_F32 && dst_dtype == CAPDEC_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
+                                       void* g, int g_dtype, float* colsum, void* stream) {
+    CAPDEC_CHECK(dx && g && M >= 0 && N > 0, "dropout_bwd_cast: bad arguments");
+    CAPDEC_CHECK(M * N < (1L << 32) || d.p <= 0.f, "dropout_bwd_cast: dropout index space exceeds 2^32 elements");
+    if (M == 0) return CAPDEC_OK;
+    const uint32_t thr = d.p > 0.f ? dropout_threshold(d.p) : 0u;
+    const float scale = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    dim3 grid((N + 1023) / 1024, (unsigned)((M + CS_ROWS - 1) / CS_ROWS)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_dtype == CAPDEC_BF16) hipLaunchKernelGGL(dropout_bwd_cast_kernel<bf16_t>, grid, block, 0, st, dx, M, N, thr, d.key0, d.key1, scale, (bf16_t*)g, colsum);
+    else hipLaunchKernelGGL(dropout_bwd_cast_kernel<float>, grid, block, 0, st, dx, M, N, thr, d.key0, d.key1, scale, (float*)g, colsum);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream) {
+    CAPDEC_CHECK(x && colsum && M >= 0 && N > 0 && ldx >= N, "colsum: bad arguments");
+    if (M == 0) return CAPDEC_OK;
+    dim3 grid((N + 1023) / 1024, (unsigned)((M + CS_ROWS - 1) / CS_ROWS)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CAPDEC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, M, N, ldx, colsum);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, M, N, ldx, colsum);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
+                                 float* out, void* stream) {
+    CAPDEC_CHECK(table && ids && out && n >= 0 && d > 0 && (d % 4) == 0, "embed_rows: bad arguments");
+    if (n == 0) return CAPDEC_OK;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, table, ids, n, d, pos_row, out);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_adam_step(float* w, const float* g, float* m, float* v, long n, int step,
+                                float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float grad_scale, void* w_bf16, void* stream) {
+    CAPDEC_CHECK(w && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+    CAPDEC_CHECK(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return CAPDEC_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w, g, m, v, n, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)w_bf16);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_greedy_update(int64_t* ids, uint8_t* done, int64_t* out, int B, int L, int t,
+                                    int64_t eos_id, int64_t pad_id, void* stream) {
+    CAPDEC_CHECK(ids && done && out && B > 0 && t >= 0 && t < L, "greedy_update: bad arguments");
+    hipLaunchKernelGGL(greedy_update_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, done, out, B, L, t, eos_id, pad_id);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}

@@ -1,0 +1,222 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point).
+
+These only translate torch tensors into pointers / leading dimensions and check
+return codes; all arithmetic happens in libcapdec.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, BF16, F32, GATE_NONE, MASK_NONE, NO_DROPOUT, AttnBwdDesc, AttnDesc, Dropout, GemmDesc,
+                   check, dtype_code, ptr, require_cuda, stream_ptr)
+
+
+def _st():
+    return stream_ptr()
+
+
+def dropout_keys(seed: int, site: int, step: int = 0, p: float = 0.0) -> Dropout:
+    """Derive the two 32-bit keys of one dropout site of one step from a seed."""
+    if p <= 0.0:
+        return Dropout(0.0, 0, 0)
+    x = (seed * 0x9E3779B97F4A7C15 + site * 0xBF58476D1CE4E5B9 + step * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & (2**64 - 1)
+    x ^= x >> 31
+    x = (x * 0xD6E8FEB86659FD93) & (2**64 - 1)
+    x ^= x >> 29
+    return Dropout(float(p), x & 0xFFFFFFFF, (x >> 32) & 0xFFFFFFFF)
+
+
+def dropout_mask(d: Dropout, n: int, device) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.load().capdec_dropout_mask(d, n, ptr(out), _st()), "capdec_dropout_mask")
+    return out
+
+
+def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None, y_out=None, mean=None, rstd=None):
+    require_cuda(img, sos, cap)
+    B, P, d = img.shape
+    L = cap.shape[1]
+    assert sos.shape == (B, 1, d) and cap.shape == (B, L, d)
+    assert img.is_contiguous() and sos.is_contiguous() and cap.is_contiguous()
+    assert img.dtype == sos.dtype == cap.dtype
+    check(_lib.load().capdec_concat_ln_fwd(ptr(img), ptr(sos), ptr(cap), dtype_code(img), ptr(pos), ptr(gamma), ptr(beta),
+                                           eps, B, P, L, d, ptr(x_out), ptr(y_out),
+                                           dtype_code(y_out) if y_out is not None else F32, ptr(mean), ptr(rstd), _st()),
+          "capdec_concat_ln_fwd")
+
+
+def ln_fwd(x, gamma, beta, y_out, mean=None, rstd=None, eps=1e-5):
+    M, d = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and y_out.is_contiguous()
+    check(_lib.load().capdec_ln_fwd(ptr(x), ptr(gamma), ptr(beta), eps, M, d, ptr(y_out), dtype_code(y_out), ptr(mean), ptr(rstd), _st()),
+          "capdec_ln_fwd")
+
+
+def ln_bwd_workspace(M, d) -> int:
+    return _lib.load().capdec_ln_bwd_workspace(M, d)
+
+
+def ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx_out, dgamma, dbeta, partial):
+    M, d = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dx_out.is_contiguous()
+    check(_lib.load().capdec_ln_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), M, d,
+                                    ptr(dx_in), ptr(dx_out), ptr(dgamma), ptr(dbeta), ptr(partial), _st()), "capdec_ln_bwd")
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "matrix operands must be 2-D with unit inner stride"
+    return t.stride(0)
+
+
+def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
+         act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
+         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None):
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
+    B is [N,K] (or [K,N] if b_kmajor)."""
+    require_cuda(A, B, Cout)
+    assert A.dtype == B.dtype
+    if M is None:
+        M = A.shape[1] if a_kmajor else A.shape[0]
+    if K is None:
+        K = A.shape[0] if a_kmajor else A.shape[1]
+    if N is None:
+        N = B.shape[1] if b_kmajor else B.shape[0]
+    d = GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = _ld(A), _ld(B), _ld(Cout)
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype, d.out_dtype = dtype_code(A), dtype_code(Cout)
+    d.bias = ptr(bias)
+    d.col_scale, d.col_scale_n = col_scale, col_scale_n
+    d.act = act
+    d.drop = drop
+    if residual is not None:
+        d.residual, d.ldr = ptr(residual), _ld(residual)
+    d.accumulate = int(accumulate)
+    if gate is not None:
+        d.gate, d.ldg, d.gate_mode, d.gate_dtype = ptr(gate), _ld(gate), gate_mode, dtype_code(gate)
+        d.gate_drop = gate_drop
+    if aux_out is not None:
+        assert aux_out.dtype == Cout.dtype
+        d.aux_out, d.ldaux = ptr(aux_out), _ld(aux_out)
+    d.colsum = ptr(colsum)
+    if kv_cache is not None:
+        dm, Bk, H, hd, smax, s0 = kv_geom
+        assert kv_cache.dtype == Cout.dtype
+        d.kv_cache, d.kv_d, d.kv_B, d.kv_H, d.kv_hd, d.kv_smax, d.kv_s0 = ptr(kv_cache), dm, Bk, H, hd, smax, s0
+    check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
+    return Cout
+
+
+def _fill_attn(desc: AttnDesc, q, k, v, o, strides, B, H, S, hd, q_start, nq, mask_mode, prefix_len, drop, lse):
+    desc.q, desc.k, desc.v, desc.o = ptr(q), ptr(k), ptr(v), ptr(o)
+    (desc.q_bs, desc.q_hs, desc.q_ss), (desc.k_bs, desc.k_hs, desc.k_ss), (desc.v_bs, desc.v_hs, desc.v_ss), \
+        (desc.o_bs, desc.o_hs, desc.o_ss) = strides
+    desc.dtype = dtype_code(q)
+    desc.B, desc.H, desc.S, desc.hd = B, H, S, hd
+    desc.q_start, desc.nq = q_start, nq
+    desc.mask_mode, desc.prefix_len = mask_mode, prefix_len
+    desc.drop = drop
+    desc.lse = ptr(lse)
+
+
+def packed_strides(B, d, hd, width):
+    """(batch, head, seq) strides of a head slice of a packed [S*B, width] row matrix."""
+    return (width, hd, B * width)
+
+
+def attn_fwd_packed(qkv, o, lse, B, H, S, hd, *, q_start=0, nq=None, mask_mode=MASK_NONE, prefix_len=0,
+                    drop: Dropout = NO_DROPOUT):
+    """qkv [S*B, 3d] (q pre-scaled), o [S*B, d], lse [B*H*S]."""
+    d = H * hd
+    nq = S - q_start if nq is None else nq
+    desc = AttnDesc()
+    s3, s1 = packed_strides(B, d, hd, 3 * d), packed_strides(B, d, hd, d)
+    _fill_attn(desc, qkv, qkv[:, d:], qkv[:, 2 * d:], o, (s3, s3, s3, s1), B, H, S, hd, q_start, nq, mask_mode, prefix_len, drop, lse)
+    check(_lib.load().capdec_attn_fwd(C.byref(desc), _st()), "capdec_attn_fwd")
+
+
+def attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, *, q_start=0, nq=None, mask_mode=MASK_NONE, prefix_len=0,
+                    drop: Dropout = NO_DROPOUT, dq_scale=1.0):
+    d = H * hd
+    nq = S - q_start if nq is None else nq
+    desc = AttnBwdDesc()
+    s3, s1 = packed_strides(B, d, hd, 3 * d), packed_strides(B, d, hd, d)
+    _fill_attn(desc.fwd, qkv, qkv[:, d:], qkv[:, 2 * d:], o, (s3, s3, s3, s1), B, H, S, hd, q_start, nq, mask_mode, prefix_len, drop, lse)
+    desc.dout, (desc.do_bs, desc.do_hs, desc.do_ss) = ptr(dout), s1
+    desc.dq, (desc.dq_bs, desc.dq_hs, desc.dq_ss) = ptr(dqkv), s3
+    desc.dk, (desc.dk_bs, desc.dk_hs, desc.dk_ss) = ptr(dqkv[:, d:]), s3
+    desc.dv, (desc.dv_bs, desc.dv_hs, desc.dv_ss) = ptr(dqkv[:, 2 * d:]), s3
+    desc.dq_scale = dq_scale
+    desc.delta = ptr(delta)
+    check(_lib.load().capdec_attn_bwd(C.byref(desc), _st()), "capdec_attn_bwd")
+
+
+def attn_decode(q, kv_cache, o, B, H, hd, smax, length):
+    check(_lib.load().capdec_attn_decode(ptr(q), ptr(kv_cache), ptr(o), dtype_code(q), B, H, hd, smax, length, _st()),
+          "capdec_attn_decode")
+
+
+def logits_ce_workspace(M, V) -> int:
+    return _lib.load().capdec_logits_ce_workspace(M, V)
+
+
+def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace):
+    M, d = h.shape
+    V = W.shape[0]
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    check(_lib.load().capdec_logits_ce_fwd(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
+                                           ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct), ptr(workspace),
+                                           workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
+
+
+def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias):
+    M, d = h.shape
+    V = W.shape[0]
+    check(_lib.load().capdec_logits_ce_bwd_slab(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
+                                                ptr(lse), gscale, v0, nv, ptr(dl), _ld(dl), ptr(dbias), _st()),
+          "capdec_logits_ce_bwd_slab")
+
+
+def logits_argmax(h, W, bias, out_ids, margin, workspace):
+    M, d = h.shape
+    V = W.shape[0]
+    check(_lib.load().capdec_logits_argmax(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(out_ids), ptr(margin),
+                                           ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "capdec_logits_argmax")
+
+
+def cast(src, dst):
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    check(_lib.load().capdec_cast(ptr(src), dtype_code(src), ptr(dst), dtype_code(dst), src.numel(), _st()), "capdec_cast")
+    return dst
+
+
+def dropout_bwd_cast(dx, drop: Dropout, g, colsum=None):
+    M, N = dx.shape
+    assert dx.dtype == torch.float32 and dx.is_contiguous() and g.is_contiguous()
+    check(_lib.load().capdec_dropout_bwd_cast(ptr(dx), M, N, drop, ptr(g), dtype_code(g), ptr(colsum), _st()), "capdec_dropout_bwd_cast")
+
+
+def colsum(x, out):
+    M, N = x.shape
+    check(_lib.load().capdec_colsum(ptr(x), dtype_code(x), M, N, _ld(x), ptr(out), _st()), "capdec_colsum")
+
+
+def embed_rows(table, ids, out, pos_row=None):
+    n, d = out.shape
+    check(_lib.load().capdec_embed_rows(ptr(table), ptr(ids), n, d, ptr(pos_row), ptr(out), _st()), "capdec_embed_rows")
+
+
+def adam_step(w, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, w_bf16=None):
+    check(_lib.load().capdec_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), step, lr, beta1, beta2, eps, weight_decay,
+                                       grad_scale, ptr(w_bf16), _st()), "capdec_adam_step")
+
+
+def greedy_update(ids, done, out, t, eos_id, pad_id):
+    B, L = out.shape
+    check(_lib.load().capdec_greedy_update(ptr(ids), ptr(done), ptr(out), B, L, t, eos_id, pad_id, _st()), "capdec_greedy_update")

@@ -1,0 +1,220 @@
+/*
+ * libcapdec -- C ABI of the MI355X captioning-decoder hot path.
+ *
+ * The reference (ocmoney/Image_caption) has no FFI: its hot path is Python calling
+ * stock torch.nn modules.  Each entry point below names the reference statements
+ * (file:line) whose arithmetic it replaces.  All pointers are caller-owned DEVICE
+ * pointers; every call is asynchronous on `stream` (a hipStream_t passed as void*)
+ * and returns 0 or a negative CAPDEC_ERR_* code (text via capdec_last_error()).
+ * The library allocates no device memory: scratch is passed in by the caller.
+ *
+ * Row convention: activations are [S*B, width] with row = s*B + b (the
+ * reference's seq-first [S,B,d] tensors, img_text_concat.py:123, flattened).
+ */
+#ifndef CAPDEC_H
+#define CAPDEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPDEC_ABI_VERSION 1
+
+enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1 };
+enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_RELU = 1, CAPDEC_ACT_GELU = 2 };
+/* attention visibility: key j visible to query i when ...
+ *   NONE          always (what decoder.py:31-38 yields for S <= 12288)
+ *   REFERENCE     j < 12288 or j <= i           (decoder.py:33-37 literally)
+ *   PREFIX_CAUSAL j < prefix_len or j <= i      (no reference counterpart) */
+enum { CAPDEC_MASK_NONE = 0, CAPDEC_MASK_REFERENCE = 1, CAPDEC_MASK_PREFIX_CAUSAL = 2 };
+enum { CAPDEC_GATE_NONE = 0, CAPDEC_GATE_RELU_OUT = 1, CAPDEC_GATE_GELU_PRE = 2 };
+
+enum {
+    CAPDEC_OK = 0,
+    CAPDEC_ERR_INVALID = -1,  /* bad argument / unsupported shape */
+    CAPDEC_ERR_LAUNCH = -2,   /* HIP launch error */
+    CAPDEC_ERR_WORKSPACE = -3 /* workspace too small */
+};
+
+int capdec_abi_version(void);
+const char* capdec_last_error(void);
+
+/* ------------------------------------------------------------------ dropout keys
+ * Dropout masks are a pure function of (key0, key1, element index); the backward
+ * entry points regenerate them from the same keys.  thr = floor(p * 2^32). */
+typedef struct {
+    float p;        /* 0 disables */
+    uint32_t key0;
+    uint32_t key1;
+} capdec_dropout;
+
+/* Write the keep-mask (1.0 / 0.0) the kernels use for `n` consecutive element
+ * indices starting at 0.  Used by tests to hand the same mask to the oracle. */
+int capdec_dropout_mask(capdec_dropout d, long n, float* out, void* stream);
+
+/* ------------------------------------------------------------------ prefix join + LayerNorm
+ * Replaces img_text_concat.py:115-123 (cat dim=1 + transpose(0,1)) fused with
+ * decoder.py:53 (norm1).  img [B,P,d], sos [B,1,d], cap [B,L,d] of `in_dtype`;
+ * optional pos [S,d] f32 added per row (no reference counterpart).
+ * Writes x [S*B,d] f32 (the residual stream), y = LN(x) of `y_dtype`,
+ * mean/rstd [S*B] f32.  Any of x / y / mean / rstd may be NULL (y NULL = join only). */
+int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int in_dtype,
+                         const float* pos, const float* gamma, const float* beta, float eps,
+                         int B, int P, int L, int d,
+                         float* x, void* y, int y_dtype, float* mean, float* rstd, void* stream);
+
+/* decoder.py:53,58 (nn.LayerNorm, eps 1e-5): y = LN(x) for x [M,d] f32. */
+int capdec_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int d,
+                  void* y, int y_dtype, float* mean, float* rstd, void* stream);
+
+/* Backward of the above (autograd of decoder.py:53,58).  dy [M,d] of dy_dtype.
+ * dx_out = dx_in (may be NULL = 0) + dLN/dx; dx_out may alias dx_in.
+ * dgamma/dbeta [d] f32 are OVERWRITTEN.  partial: scratch of
+ * capdec_ln_bwd_workspace(M,d) bytes. */
+long capdec_ln_bwd_workspace(long M, int d);
+int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                  const float* mean, const float* rstd, long M, int d,
+                  const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+                  void* partial, void* stream);
+
+/* ------------------------------------------------------------------ GEMM + fused epilogue
+ * C[m,n] = epilogue( sum_k A(m,k) * B(n,k) ).  Replaces every nn.Linear of
+ * decoder.py:54,59,62,66 and their autograd products (dgrad / wgrad):
+ *   forward  y = x W^T      : A=x [M,K],  B=W [N,K]            (a_kmajor=0, b_kmajor=0)
+ *   dgrad    dx = dy W      : A=dy [M,K], B=W stored [K,N]     (b_kmajor=1)
+ *   wgrad    dW = dy^T x    : A=dy stored [K,M], B=x stored [K,N]  (both kmajor)
+ * Epilogue order: + bias[n]; * col_scale for n < col_scale_n; aux_out = value
+ * (pre-activation); activation; * gate; dropout; + residual; (+ C when accumulate);
+ * colsum[n] += value (atomic); store.  in_dtype BF16 runs on MFMA with f32
+ * accumulation, F32 is an exact-f32 validation path. */
+typedef struct {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    long lda, ldb, ldc;          /* in elements */
+    int a_kmajor, b_kmajor;
+    int in_dtype, out_dtype;
+    const float* bias;           /* [N] or NULL */
+    float col_scale; int col_scale_n;
+    int act;                     /* CAPDEC_ACT_* */
+    capdec_dropout drop;         /* on the output, element index m*N+n */
+    const float* residual; long ldr;
+    int accumulate;              /* f32 out only */
+    /* gate: multiplies by the derivative of activation+dropout of a forward GEMM:
+     *  RELU_OUT: gate tensor = saved forward output; factor = (g != 0) / (1 - gate_drop.p)
+     *  GELU_PRE: gate tensor = saved pre-activation z; factor = gelu'(z) * keep / (1 - p) */
+    const void* gate; long ldg; int gate_mode; int gate_dtype; capdec_dropout gate_drop;
+    void* aux_out; long ldaux;   /* out_dtype, NULL = off */
+    float* colsum;               /* [N] f32 atomically += column sums of the stored values */
+    /* K/V-cache scatter (greedy decoding): columns >= kv_d go to
+     * kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_d go to C. */
+    void* kv_cache; int kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
+} capdec_gemm_desc;
+
+int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------ attention
+ * Replaces nn.MultiheadAttention's core (decoder.py:54; torch functional.py
+ * baddbmm -> softmax -> dropout -> bmm) for all heads of all sequences.
+ * q/k/v/o are addressed as base + b*bstride + h*hstride + s*sstride + j (elements),
+ * so both the packed [S*B,3d] projection output and a [B,H,S,hd] cache work.
+ * q must already carry the hd^-0.5 scale.  Queries q_start..q_start+nq-1 of each
+ * sequence are computed against keys 0..S-1.  lse [B*H*S] f32 receives
+ * log-sum-exp of the masked scores (needed by the backward). */
+typedef struct {
+    const void* q; const void* k; const void* v; void* o;
+    long q_bs, q_hs, q_ss;  long k_bs, k_hs, k_ss;  long v_bs, v_hs, v_ss;  long o_bs, o_hs, o_ss;
+    int dtype;
+    int B, H, S, hd;
+    int q_start, nq;
+    int mask_mode, prefix_len;
+    capdec_dropout drop;     /* on probabilities; index ((b*H+h)*S+q)*S+key */
+    float* lse;
+} capdec_attn_desc;
+
+int capdec_attn_fwd(const capdec_attn_desc* desc, void* stream);
+
+/* Backward: given do (same addressing as o) produce dq, dk, dv (addressing given
+ * by dq_*, dk_*, dv_* strides).  delta [B*H*S] f32 scratch (rowsum(do*o)).
+ * Queries outside [q_start, q_start+nq) contribute nothing; dq rows outside are
+ * not written. */
+typedef struct {
+    capdec_attn_desc fwd;    /* same q,k,v,o,lse as the forward call */
+    const void* dout; long do_bs, do_hs, do_ss;
+    void* dq; long dq_bs, dq_hs, dq_ss;
+    void* dk; long dk_bs, dk_hs, dk_ss;
+    void* dv; long dv_bs, dv_hs, dv_ss;
+    float dq_scale;          /* dq is multiplied by this (hd^-0.5 when q was pre-scaled) */
+    float* delta;
+} capdec_attn_bwd_desc;
+
+int capdec_attn_bwd(const capdec_attn_bwd_desc* desc, void* stream);
+
+/* One query row per sequence against a K/V cache [B][H][2][smax][hd]
+ * (greedy decoding; no reference counterpart: the reference has no generation).
+ * q [B, H*hd] (scaled), o [B, H*hd]; keys 0..len-1 are visible. */
+int capdec_attn_decode(const void* q, const void* kv_cache, void* o, int dtype,
+                       int B, int H, int hd, int smax, int len, void* stream);
+
+/* ------------------------------------------------------------------ vocabulary projection + cross-entropy
+ * Replaces decoder.py:66 (output_projection) on the scored rows only, the
+ * slice/permute/reshape of decoder.py:172-179, nn.CrossEntropyLoss() (mean over
+ * all rows, no ignore_index, decoder.py:140) and the argmax accuracy of
+ * decoder.py:182-183, without materialising logits.
+ * h [M,d] (M = L*B scored rows, row = l*B + b), W [V,d], bias [V] f32,
+ * labels [B,L] int64.  Outputs: lse [M], argmax [M] int32, loss_sum[0] (sum of
+ * per-row losses), correct[0] (int32).  workspace: capdec_logits_ce_workspace bytes. */
+long capdec_logits_ce_workspace(long M, int V);
+int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
+                         long M, int V, int d, long ldh, long ldw,
+                         const int64_t* labels, int B, int L,
+                         float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                         void* workspace, long workspace_bytes, void* stream);
+
+/* Backward of the mean loss w.r.t. logits, one vocabulary slab [v0, v0+nv):
+ * dl[m, n-v0] = (exp(z[m,n] - lse[m]) - [n == label[m]]) * gscale, written to
+ * dl [M, ld_dl] of `dtype` (columns nv..ld_dl-1 zero-filled); dbias[v0+..] +=
+ * column sums (atomic, f32).  The caller then forms dH += dl W_slab and
+ * dW_slab = dl^T H with capdec_gemm_bias_act. */
+int capdec_logits_ce_bwd_slab(const void* h, const void* W, const float* bias, int dtype,
+                              long M, int V, int d, long ldh, long ldw,
+                              const int64_t* labels, int B, int L, const float* lse, float gscale,
+                              int v0, int nv, void* dl, long ld_dl, float* dbias, void* stream);
+
+/* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
+ * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
+int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
+                         long M, int V, int d, long ldh, long ldw,
+                         int64_t* out_ids, float* margin,
+                         void* workspace, long workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ element-wise helpers */
+/* dst = cast(src) for n elements */
+int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* Backward of `x + dropout(y)` w.r.t. y (decoder.py:55,63): g[m,n] = dx[m,n] * keep / (1-p)
+ * cast to g_dtype; colsum[n] (optional, f32, atomic +=) receives the column sums
+ * (= bias gradient of the Linear that produced y). */
+int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
+                            void* g, int g_dtype, float* colsum, void* stream);
+/* colsum[n] += sum_m x[m,n]  (bias gradients) */
+int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream);
+/* rows of a token-embedding table: out[i,:] = table[ids[i],:] (+ pos row if given); out f32 */
+int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
+                      float* out, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) with coupled L2 (decoder.py:135-139,190)
+ * over a flat f32 parameter buffer; optionally refreshes a bf16 shadow copy used by
+ * the MFMA kernels.  grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int capdec_adam_step(float* w, const float* g, float* m, float* v, long n, int step,
+                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float grad_scale, void* w_bf16, void* stream);
+
+/* Greedy bookkeeping: ids[b] <- pad where done[b]; done[b] |= ids[b]==eos; out[b*L+t] = ids[b]. */
+int capdec_greedy_update(int64_t* ids, uint8_t* done, int64_t* out, int B, int L, int t,
+                         int64_t eos_id, int64_t pad_id, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPDEC_H */

@@ -1,0 +1,349 @@
+"""Per-entry-point checks of libcapdec on a real MI355X, each against a plain torch
+float32 computation of the same op on the same inputs (bf16 inputs are rounded
+first, then the reference is computed in f32).  Tolerances: f32 paths 1e-4
+relative to the output scale; bf16 paths 2e-2 (bf16 has 8 significant bits;
+accumulation is f32)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from image_caption_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def close(a, b, tol, what=""):
+    a = a.float()
+    b = b.float()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+# ---------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 136), (77, 503, 64), (1000, 72, 520), (33, 40, 8), (64, 136, 44)])
+def test_gemm_layouts(dtype, tol, akm, bkm, M, N, K):
+    A = rnd(M, K, dtype=dtype, seed=1)
+    B = rnd(N, K, dtype=dtype, seed=2)
+    if dtype == torch.bfloat16 and ((akm and M % 8) or (bkm and N % 8)):
+        pytest.skip("k-major bf16 operands need a leading dimension that is a multiple of 8")
+    def padded(t):      # same values, row pitch rounded up to 8 elements, padding poisoned
+        buf = torch.full((t.shape[0], (t.shape[1] + 7) // 8 * 8), float("nan"), device=DEV, dtype=t.dtype)
+        buf[:, :t.shape[1]] = t
+        return buf[:, :t.shape[1]]
+    Aop = A.t().contiguous() if akm else padded(A)
+    Bop = B.t().contiguous() if bkm else padded(B)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Aop, Bop, out, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm)
+    ref = A.float() @ B.float().t()
+    close(out, ref, tol, "gemm")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float32, 3e-5)])
+def test_gemm_epilogue_forward(dtype, tol):
+    M, N, K = 300, 264, 192
+    A, B = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.1, seed=4)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    drop = ops.dropout_keys(7, 3, 1, p=0.25)
+    keep = ops.dropout_mask(drop, M * N, DEV).reshape(M, N)
+    assert 0.70 < keep.mean().item() < 0.80
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm(A, B, out, bias=bias, col_scale=0.5, col_scale_n=100, act=_lib.ACT_RELU, drop=drop, residual=res,
+             aux_out=aux, colsum=cs)
+    z = A.float() @ B.float().t() + bias
+    z[:, :100] *= 0.5
+    ref = torch.relu(z) * keep / 0.75 + res
+    close(aux, z, tol, "aux")
+    close(out, ref, tol, "epilogue")
+    close(cs, out.float().sum(0), 2e-3, "colsum")
+    # gelu + accumulate into f32
+    out2 = res.clone()
+    ops.gemm(A, B, out2, bias=bias, act=_lib.ACT_GELU, accumulate=True)
+    z2 = A.float() @ B.float().t() + bias
+    close(out2, torch.nn.functional.gelu(z2) + res, tol, "gelu+accumulate")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float32, 3e-5)])
+def test_gemm_gates(dtype, tol):
+    M, N, K = 260, 136, 72
+    A, B = rnd(M, K, dtype=dtype, seed=8), rnd(K, N, dtype=dtype, scale=0.2, seed=9)     # B stored [K,N]
+    saved = torch.relu(rnd(M, N, seed=10)).to(dtype)
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm(A, B, out, b_kmajor=True, gate=saved, gate_mode=_lib.GATE_RELU_OUT, gate_drop=_lib.Dropout(0.2, 0, 0))
+    ref = (A.float() @ B.float()) * (saved.float() != 0) / 0.8
+    close(out, ref, tol, "relu gate")
+    z = rnd(M, N, seed=11).to(dtype)
+    gd = ops.dropout_keys(1, 2, 3, p=0.1)
+    keep = ops.dropout_mask(gd, M * N, DEV).reshape(M, N)
+    ops.gemm(A, B, out, b_kmajor=True, gate=z, gate_mode=_lib.GATE_GELU_PRE, gate_drop=gd)
+    zf = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zf).sum().backward()
+    ref = (A.float() @ B.float()) * zf.grad * keep / 0.9
+    close(out, ref, tol, "gelu gate")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_kv_scatter(dtype):
+    Bb, H, hd, smax, s0, ns = 3, 2, 32, 10, 4, 2
+    d = H * hd
+    M = ns * Bb
+    x = rnd(M, 64, dtype=dtype, seed=12)
+    W = rnd(3 * d, 64, dtype=dtype, scale=0.2, seed=13)
+    qout = torch.zeros(M, d, device=DEV, dtype=dtype)
+    cache = torch.zeros(Bb, H, 2, smax, hd, device=DEV, dtype=dtype)
+    ops.gemm(x, W, qout, col_scale=0.25, col_scale_n=d, kv_cache=cache, kv_geom=(d, Bb, H, hd, smax, s0))
+    y = x.float() @ W.float().t()
+    close(qout, y[:, :d] * 0.25, 1.5e-2, "q")
+    kv = y[:, d:].reshape(ns, Bb, 2, H, hd).permute(1, 3, 2, 0, 4)          # [B,H,2,ns,hd]
+    close(cache[:, :, :, s0:s0 + ns], kv, 1.5e-2, "kv")
+    assert cache[:, :, :, :s0].abs().max().item() == 0 and cache[:, :, :, s0 + ns:].abs().max().item() == 0
+
+
+# ---------------------------------------------------------------------------- LayerNorm / concat
+@pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("d", [64, 768])
+def test_concat_ln_fwd_bwd(ydt, d):
+    B, P, L = 5, 12, 8
+    S = P + 1 + L
+    img, sos, cap = rnd(B, P, d, seed=20), rnd(B, 1, d, seed=21), rnd(B, L, d, seed=22)
+    pos = rnd(S, d, seed=23)
+    gamma, beta = 1 + 0.1 * rnd(d, seed=24), 0.1 * rnd(d, seed=25)
+    x = torch.empty(S * B, d, device=DEV)
+    y = torch.empty(S * B, d, device=DEV, dtype=ydt)
+    mean, rstd = torch.empty(S * B, device=DEV), torch.empty(S * B, device=DEV)
+    ops.concat_ln_fwd(img, sos, cap, gamma, beta, pos=pos, x_out=x, y_out=y, mean=mean, rstd=rstd)
+    xr = (torch.cat([img, sos, cap], 1).transpose(0, 1) + pos[:, None]).reshape(S * B, d)
+    assert torch.equal(x, xr)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gamma, beta, 1e-5)
+    close(y, yr, 1e-2 if ydt == torch.bfloat16 else 2e-6, "ln")
+    y2 = torch.empty_like(y)
+    ops.ln_fwd(x, gamma, beta, y2, mean, rstd)
+    assert torch.equal(y2, y)
+    # backward
+    dy = rnd(S * B, d, seed=26).to(ydt)
+    dx_in = rnd(S * B, d, seed=27)
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    ws = torch.empty(ops.ln_bwd_workspace(S * B, d), dtype=torch.uint8, device=DEV)
+    ops.ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dg, db, ws)
+    xg = xr.clone().requires_grad_(True)
+    gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xg, (d,), gg, bg, 1e-5).backward(dy.float())
+    close(dx, xg.grad + dx_in, 1e-5, "dx")
+    close(dg, gg.grad, 1e-5, "dgamma")
+    close(db, bg.grad, 1e-5, "dbeta")
+
+
+# ---------------------------------------------------------------------------- attention
+def torch_attention(qkv, B, H, S, hd, mask, keep, p):
+    d = H * hd
+    q, k, v = qkv.float().reshape(S, B, 3, H, hd).permute(2, 1, 3, 0, 4)       # [B,H,S,hd] each
+    s = q @ k.transpose(-1, -2) + mask
+    pr = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    o = (pr @ v).permute(2, 0, 1, 3).reshape(S * B, d)
+    return o, lse
+
+
+def mask_for(S, mode, prefix):
+    i = torch.arange(S, device=DEV)[:, None]
+    j = torch.arange(S, device=DEV)[None, :]
+    if mode == _lib.MASK_NONE:
+        vis = torch.ones(S, S, dtype=torch.bool, device=DEV)
+    elif mode == _lib.MASK_REFERENCE:
+        vis = (j < 12288) | (j <= i)
+    else:
+        vis = (j < prefix) | (j <= i)
+    return torch.zeros(S, S, device=DEV).masked_fill(~vis, float("-inf"))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("B,H,S,hd,mode,prefix,p", [
+    (2, 2, 21, 32, _lib.MASK_NONE, 0, 0.0),
+    (2, 8, 229, 96, _lib.MASK_REFERENCE, 0, 0.0),
+    (3, 2, 70, 96, _lib.MASK_PREFIX_CAUSAL, 37, 0.0),
+    (2, 3, 130, 64, _lib.MASK_PREFIX_CAUSAL, 100, 0.1),
+    (1, 2, 290, 96, _lib.MASK_NONE, 0, 0.1),
+    (1, 1, 200, 128, _lib.MASK_REFERENCE, 0, 0.0),
+])
+def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
+    d = H * hd
+    qkv = rnd(S * B, 3 * d, dtype=dtype, scale=0.7, seed=30)
+    drop = ops.dropout_keys(3, 1, 5, p=p)
+    keep = ops.dropout_mask(drop, B * H * S * S, DEV).reshape(B, H, S, S) if p > 0 else None
+    o = torch.full((S * B, d), float("nan"), device=DEV, dtype=dtype)
+    lse = torch.empty(B * H * S, device=DEV)
+    ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, mask_mode=mode, prefix_len=prefix, drop=drop)
+    qr = qkv.float().requires_grad_(True)
+    oref, lref = torch_attention(qr, B, H, S, hd, mask_for(S, mode, prefix), keep, p)
+    close(o, oref, tol, "o")
+    close(lse.reshape(B, H, S), lref, 1e-2 if dtype == torch.bfloat16 else 1e-5, "lse")
+    dout = rnd(S * B, d, dtype=dtype, seed=31)
+    oref.backward(dout.float())
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B * H * S, device=DEV)
+    ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, mask_mode=mode, prefix_len=prefix, drop=drop, dq_scale=1.0)
+    close(dqkv[:, :d], qr.grad[:, :d], tol * 1.5, "dq")
+    close(dqkv[:, d:2 * d], qr.grad[:, d:2 * d], tol * 1.5, "dk")
+    close(dqkv[:, 2 * d:], qr.grad[:, 2 * d:], tol * 1.5, "dv")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+def test_attention_query_range(dtype, tol):
+    # only the last nq queries are computed (scored rows of the last block)
+    B, H, S, hd, nq = 2, 2, 50, 32, 9
+    d = H * hd
+    qkv = rnd(S * B, 3 * d, dtype=dtype, scale=0.7, seed=32)
+    o = torch.zeros(S * B, d, device=DEV, dtype=dtype)
+    lse = torch.zeros(B * H * S, device=DEV)
+    ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, q_start=S - nq, nq=nq)
+    qr = qkv.float().requires_grad_(True)
+    oref, _ = torch_attention(qr, B, H, S, hd, mask_for(S, 0, 0), None, 0.0)
+    close(o[(S - nq) * B:], oref[(S - nq) * B:], tol, "o tail")
+    assert o[:(S - nq) * B].abs().max().item() == 0
+    dout = rnd(S * B, d, dtype=dtype, seed=33)
+    dout[:(S - nq) * B] = 0
+    oref.backward(dout.float())
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B * H * S, device=DEV)
+    ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, q_start=S - nq, nq=nq)
+    close(dqkv, qr.grad, tol * 1.5, "dqkv")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("H,hd,smax,length", [(8, 96, 229, 229), (2, 32, 21, 14), (3, 64, 290, 257), (2, 128, 40, 1)])
+def test_attention_decode(dtype, tol, H, hd, smax, length):
+    B = 5
+    q = rnd(B, H * hd, dtype=dtype, scale=0.5, seed=34)
+    cache = rnd(B, H, 2, smax, hd, dtype=dtype, seed=35)
+    o = torch.empty(B, H * hd, device=DEV, dtype=dtype)
+    ops.attn_decode(q, cache, o, B, H, hd, smax, length)
+    qf = q.float().reshape(B, H, 1, hd)
+    k, v = cache[:, :, 0, :length].float(), cache[:, :, 1, :length].float()
+    ref = (torch.softmax(qf @ k.transpose(-1, -2), -1) @ v).reshape(B, H * hd)
+    close(o, ref, tol, "decode")
+
+
+# ---------------------------------------------------------------------------- vocabulary projection + CE
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("B,L,V,d", [(3, 8, 503, 64), (16, 32, 50260, 768)])
+def test_logits_ce(dtype, tol, B, L, V, d):
+    M = B * L
+    h = rnd(M, d, dtype=dtype, seed=40)
+    W = rnd(V, d, dtype=dtype, scale=1 / math.sqrt(d), seed=41)
+    bias = rnd(V, scale=0.05, seed=42)
+    labels = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(43)).to(DEV)
+    labels[0, 0], labels[-1, -1] = V - 1, 0
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    lse = torch.empty(M, device=DEV)
+    amax = torch.empty(M, dtype=torch.int32, device=DEV)
+    loss_sum, correct = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    ops.logits_ce_fwd(h, W, bias, labels, B, L, lse, amax, loss_sum, correct, ws)
+    hr = h.float().requires_grad_(True)
+    Wr = W.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    z = hr @ Wr.t() + br                                     # row m = l*B + b
+    tgt = labels.t().reshape(-1)
+    loss_ref = torch.nn.functional.cross_entropy(z, tgt)
+    close(lse, torch.logsumexp(z, -1), 1e-3 if dtype == torch.bfloat16 else 1e-6, "lse")
+    assert abs(loss_sum.item() / M - loss_ref.item()) < (2e-3 if dtype == torch.bfloat16 else 2e-5) * loss_ref.item()
+    top2 = z.topk(2, -1)
+    decided = (top2.values[:, 0] - top2.values[:, 1]) > (0.05 if dtype == torch.bfloat16 else 1e-4)
+    assert torch.equal(amax[decided].long(), top2.indices[decided, 0])
+    if dtype == torch.float32:
+        assert correct.item() == int((z.argmax(-1) == tgt).sum())
+    # argmax entry point
+    ids = torch.empty(M, dtype=torch.int64, device=DEV)
+    margin = torch.empty(M, device=DEV)
+    ops.logits_argmax(h, W, bias, ids, margin, ws)
+    assert torch.equal(ids[decided], top2.indices[decided, 0])
+    close(margin, top2.values[:, 0] - top2.values[:, 1], 0.1 if dtype == torch.bfloat16 else 1e-3, "margin")
+    # backward, slab by slab
+    loss_ref.backward()
+    dbias = torch.zeros(V, device=DEV)
+    dH = torch.zeros(M, d, device=DEV)
+    dW = torch.empty(V, d, device=DEV)
+    slab = 256 if V < 1000 else 8192
+    for v0 in range(0, V, slab):
+        nv = min(slab, V - v0)
+        ld = (nv + 127) // 128 * 128
+        dl = torch.full((M, ld), float("nan"), device=DEV, dtype=dtype)
+        ops.logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, 1.0 / M, v0, nv, dl, dbias)
+        dl_ref = (torch.softmax(z.detach(), -1) - torch.nn.functional.one_hot(tgt, V))[:, v0:v0 + nv] / M
+        close(dl[:, :nv], dl_ref, 2e-2 if dtype == torch.bfloat16 else 1e-5, "dl")
+        assert dl[:, nv:].abs().max().item() == 0 if ld > nv else True
+        ops.gemm(dl, W[v0:], dH, M=M, N=d, K=nv, b_kmajor=True, accumulate=True)
+        ops.gemm(dl, h, dW[v0:v0 + nv], M=nv, N=d, K=M, a_kmajor=True, b_kmajor=True)
+    close(dbias, br.grad, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dbias")
+    close(dH, hr.grad, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dH")
+    close(dW, Wr.grad, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dW")
+
+
+# ---------------------------------------------------------------------------- element-wise
+def test_elementwise_and_adam():
+    M, N = 130, 72
+    dx = rnd(M, N, seed=50)
+    drop = ops.dropout_keys(9, 4, 2, p=0.1)
+    keep = ops.dropout_mask(drop, M * N, DEV).reshape(M, N)
+    g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=DEV)
+    ops.dropout_bwd_cast(dx, drop, g, cs)
+    ref = dx * keep / 0.9
+    close(g, ref, 1e-2, "dropout_bwd_cast")
+    close(cs, ref.sum(0), 1e-5, "colsum of dropout_bwd_cast")
+    cs2 = torch.zeros(N, device=DEV)
+    ops.colsum(g, cs2)
+    close(cs2, g.float().sum(0), 1e-5, "colsum")
+    b = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.cast(dx, b)
+    assert torch.equal(b, dx.to(torch.bfloat16))
+    # embedding rows
+    table = rnd(40, 64, seed=51)
+    ids = torch.tensor([3, 39, 0, 3], device=DEV)
+    out = torch.empty(4, 64, device=DEV)
+    ops.embed_rows(table, ids, out, pos_row=table[1])
+    assert torch.equal(out, table[ids] + table[1])
+    # Adam vs torch.optim.Adam (coupled weight decay), 3 steps, odd length
+    n = 1003
+    w0 = rnd(n, seed=52)
+    w = w0.clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    wb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    pw = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([pw], lr=1e-3, weight_decay=0.01)
+    for step in range(1, 4):
+        gr = rnd(n, seed=60 + step)
+        ops.adam_step(w, gr, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 0.01, w_bf16=wb)
+        pw.grad = gr.clone()
+        opt.step()
+    close(w, pw.data, 2e-6, "adam")
+    assert torch.equal(wb, w.to(torch.bfloat16))
+    # greedy bookkeeping
+    ids = torch.tensor([5, 7, 9], device=DEV)
+    done = torch.tensor([0, 1, 0], dtype=torch.uint8, device=DEV)
+    outb = torch.zeros(3, 4, dtype=torch.int64, device=DEV)
+    ops.greedy_update(ids, done, outb, 2, 9, 11)
+    assert ids.tolist() == [5, 11, 9] and done.tolist() == [0, 1, 1] and outb[:, 2].tolist() == [5, 11, 9]
+
+
+def test_errors_are_loud():
+    A = rnd(16, 12, dtype=torch.bfloat16)      # leading dimension 12 is not a multiple of 8
+    B = rnd(16, 12, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.gemm(A, B, torch.empty(16, 16, device=DEV))
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.gemm(A.cpu(), B.cpu(), torch.empty(16, 16))
