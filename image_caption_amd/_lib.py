@@ -46,7 +46,7 @@ class GemmDesc(C.Structure):
         ("gate", c_void_p), ("ldg", c_long), ("gate_mode", c_int), ("gate_dtype", c_int), ("gate_drop", Dropout),
         ("aux_out", c_void_p), ("ldaux", c_long),
         ("colsum", c_void_p),
-        ("kv_cache", c_void_p), ("kv_d", c_int), ("kv_B", c_int), ("kv_H", c_int), ("kv_hd", c_int),
+        ("kv_cache", c_void_p), ("kv_q", c_int), ("kv_d", c_int), ("kv_B", c_int), ("kv_H", c_int), ("kv_hd", c_int),
         ("kv_smax", c_int), ("kv_s0", c_int),
     ]
 

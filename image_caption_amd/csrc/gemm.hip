@@ -44,7 +44,7 @@ struct GemmArgs {
     float gate_scale; uint32_t gate_thr, gate_k0, gate_k1;
     void* aux_out; long ldaux;
     float* colsum;
-    void* kv_cache; int kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
+    void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
     // cross-entropy epilogues
     const int64_t* labels; int ce_B, ce_L; int ce_col0;
     float* pmax; float* psum; float* psec; int* parg; float* zlabel; int np;
@@ -202,9 +202,9 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
                 csum[e] += v[e];
             }
         }
-        if (p.kv_cache && n >= p.kv_d) {
+        if (p.kv_cache && n >= p.kv_q) {
             // K/V columns: cache[b][h][k|v][kv_s0 + s][j]
-            const int nn = n - p.kv_d;
+            const int nn = n - p.kv_q;
             const int which = nn / p.kv_d, rem = nn - which * p.kv_d;
             const int hh = rem / p.kv_hd, j = rem - hh * p.kv_hd;
             const long s = m / p.kv_B, b = m - s * p.kv_B;
@@ -616,12 +616,12 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     a.gate_scale = d->gate_drop.p > 0.f ? 1.0f / (1.0f - d->gate_drop.p) : 1.0f;
     a.aux_out = d->aux_out; a.ldaux = d->ldaux;
     a.colsum = d->colsum;
-    a.kv_cache = d->kv_cache; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
+    a.kv_cache = d->kv_cache; a.kv_q = d->kv_q; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
     a.kv_smax = d->kv_smax; a.kv_s0 = d->kv_s0;
     if (a.kv_cache) {
         CAPDEC_CHECK(a.kv_d > 0 && a.kv_B > 0 && a.kv_H > 0 && a.kv_hd > 0 && a.kv_H * a.kv_hd == a.kv_d && (a.kv_hd % 4) == 0,
                      "gemm: inconsistent kv scatter geometry");
-        CAPDEC_CHECK(a.N == 3 * a.kv_d && (a.M % a.kv_B) == 0 && a.kv_s0 + a.M / a.kv_B <= a.kv_smax,
+        CAPDEC_CHECK((a.kv_q == 0 || a.kv_q == a.kv_d) && a.N == a.kv_q + 2 * a.kv_d && (a.M % a.kv_B) == 0 && a.kv_s0 >= 0 && a.kv_s0 + a.M / a.kv_B <= a.kv_smax,
                      "gemm: kv scatter out of range (N=%d, M=%d, s0=%d, smax=%d)", a.N, a.M, a.kv_s0, a.kv_smax);
     }
     return launch_gemm<EPI_STD>(a, d->in_dtype, (hipStream_t)stream);

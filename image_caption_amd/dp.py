@@ -1,0 +1,100 @@
+"""Data-parallel gradient exchange: bucketed all-reduce overlapped with backward.
+
+The reference is single-process (there is nothing to port); the batch dimension of
+``decoder_inputs`` / ``caption_labels`` (decoder.py:163,166) is independent and the
+loss is a mean (decoder.py:140), so each rank takes a slice of the batch and the
+ranks sum their gradients.
+
+The flat gradient buffer of ``ParamStore`` is laid out in the order the backward
+FINISHES gradients: vocabulary-weight slabs, vocabulary bias, then the blocks from
+last to first.  The finished region is therefore always a growing prefix of the
+buffer, and a bucket is simply the next contiguous slice of it.  Each bucket's
+all-reduce (RCCL over xGMI when the backend is "nccl") is issued asynchronously
+as soon as the slice is complete; the remaining backward kernels keep running on
+the compute stream.  ``finish`` makes the compute stream wait for all buckets
+before the optimiser kernel reads the gradients.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+HEAD_W, HEAD_B = "output_projection.weight", "output_projection.bias"
+
+
+class GradReducer:
+    def __init__(self, store, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
+        self.store = store
+        self.group = process_group
+        self.enabled = bool(dist is not None and dist.is_available() and dist.is_initialized()
+                            and dist.get_world_size(process_group) > 1)
+        self.world_size = dist.get_world_size(process_group) if self.enabled else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = overlap
+        self.ready_end = 0       # gradients in g[:ready_end] are final
+        self.sent_end = 0        # g[:sent_end] has been handed to all-reduce
+        self.works: List = []
+        self.bucket_log: List = []   # (start, end) of every bucket of the last step
+        # end offset (exclusive, padded) of every layout entry, in layout order
+        self._ends = {}
+        layout = store.layout
+        for idx, (key, shape, off) in enumerate(layout):
+            nxt = layout[idx + 1][2] if idx + 1 < len(layout) else store.numel
+            self._ends[key] = nxt
+        self._block_end = {}
+        nb = store.geo.n_blocks
+        for key, shape, off in layout:
+            if key in (HEAD_W, HEAD_B):
+                continue
+            i = int(key.split(".")[1]) if key.startswith("blocks.") else 0
+            self._block_end[i] = max(self._block_end.get(i, 0), self._ends[key])
+
+    def begin(self):
+        self.ready_end = 0
+        self.sent_end = 0
+        self.works = []
+        self.bucket_log = []
+
+    def _launch(self, end: int):
+        if end <= self.sent_end:
+            return
+        sl = self.store.g[self.sent_end:end]
+        self.bucket_log.append((self.sent_end, end))
+        self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.sent_end = end
+
+    def on_grad_ready(self, key, v0: int, nv: int):
+        """Called by the engine when a piece of the gradient is final:
+        (HEAD_W, v0, nv) vocabulary rows [v0, v0+nv); (HEAD_B, ..) the bias;
+        (("block", i), ..) every tensor of block i."""
+        if not self.enabled:
+            return
+        if key == HEAD_W:
+            off, shape = self.store.offsets[HEAD_W]
+            end = off + (v0 + nv) * shape[1]
+            if v0 + nv >= shape[0]:
+                end = self._ends[HEAD_W]
+        elif key == HEAD_B:
+            end = self._ends[HEAD_B]
+        else:
+            end = self._block_end[key[1]]
+        self.ready_end = max(self.ready_end, end)
+        if self.overlap and self.ready_end - self.sent_end >= self.bucket_elems:
+            self._launch(self.ready_end)
+
+    def finish(self):
+        if not self.enabled:
+            return
+        self._launch(self.store.numel if self.ready_end >= self.store.numel else self.ready_end)
+        if self.sent_end < self.store.numel:          # anything never announced (defensive)
+            self._launch(self.store.numel)
+        for w in self.works:
+            w.wait()
+        self.works = []

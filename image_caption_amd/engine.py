@@ -1,0 +1,549 @@
+"""Host-side orchestration of the captioning hot path on libcapdec kernels.
+
+``DecoderEngine`` sequences the kernels of one training step (prefix join ->
+blocks forward -> fused vocabulary projection + cross-entropy -> backward) and of
+KV-cached greedy decoding.  It owns only bookkeeping and reusable device buffers;
+every floating-point operation on activations happens in libcapdec.so.
+
+What each stage replaces in the reference:
+  prefix join                 img_text_concat.py:115-123
+  block forward               decoder.py:53-63
+  scored-row vocab + CE       decoder.py:66,172-185
+  backward                    decoder.py:189 (autograd of the above)
+  greedy decoding             no counterpart (the reference has no generation code)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import ACT_GELU, ACT_RELU, GATE_GELU_PRE, GATE_RELU_OUT, MASK_NONE, MASK_PREFIX_CAUSAL, MASK_REFERENCE
+
+BLOCK_PARAM_SHAPES = (
+    ("self_attn.in_proj_weight", lambda d, ff: (3 * d, d)),
+    ("self_attn.in_proj_bias", lambda d, ff: (3 * d,)),
+    ("self_attn.out_proj.weight", lambda d, ff: (d, d)),
+    ("self_attn.out_proj.bias", lambda d, ff: (d,)),
+    ("linear1.weight", lambda d, ff: (ff, d)),
+    ("linear1.bias", lambda d, ff: (ff,)),
+    ("linear2.weight", lambda d, ff: (d, ff)),
+    ("linear2.bias", lambda d, ff: (d,)),
+    ("norm1.weight", lambda d, ff: (d,)),
+    ("norm1.bias", lambda d, ff: (d,)),
+    ("norm2.weight", lambda d, ff: (d,)),
+    ("norm2.bias", lambda d, ff: (d,)),
+)
+MATRIX_KEYS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight")
+HEAD_W, HEAD_B = "output_projection.weight", "output_projection.bias"
+
+_MASKS = {"none": MASK_NONE, "reference": MASK_REFERENCE, "prefix_causal": MASK_PREFIX_CAUSAL}
+_ACTS = {"relu": ACT_RELU, "gelu": ACT_GELU}
+
+
+@dataclass
+class EngineOptions:
+    """Knobs that have no counterpart in the reference's config.py."""
+    compute_dtype: torch.dtype = torch.bfloat16   # bfloat16 = MFMA path, float32 = exact validation path
+    mask_mode: str = "reference"                  # decoder.py:31-38 literally; "prefix_causal" / "none"
+    activation: str = "relu"                      # decoder.py:60; "gelu" is an extension
+    vocab_slab: int = 8192                        # vocabulary columns per backward slab
+    scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
+    dropout_seed: int = 42
+
+
+@dataclass
+class ModelGeometry:
+    d_model: int
+    nhead: int
+    dim_feedforward: int
+    vocab_size: int
+    n_blocks: int = 1
+    dropout: float = 0.0
+
+    @property
+    def hd(self) -> int:
+        return self.d_model // self.nhead
+
+
+def block_key(i: int, name: str, n_blocks: int) -> str:
+    """state_dict key of a block parameter: the reference's own names for a
+    one-block model, ``blocks.{i}.<name>`` for stacked blocks (i >= 1)."""
+    return name if i == 0 else f"blocks.{i}.{name}"
+
+
+class ParamStore:
+    """All trainable tensors in ONE flat f32 buffer (+ gradient, Adam moments and a
+    compute-dtype shadow of the matrices), with named views.  One flat buffer means
+    one fused Adam launch and contiguous all-reduce buckets."""
+
+    def __init__(self, geo: ModelGeometry, device, compute_dtype, with_optimizer_state: bool):
+        self.geo = geo
+        self.compute_dtype = compute_dtype
+        d, ff, V = geo.d_model, geo.dim_feedforward, geo.vocab_size
+        self.layout: List = []            # (key, shape, offset)
+        off = 0
+        # head first: its gradient is produced first in backward, so its all-reduce can start first
+        for key, shape in ((HEAD_W, (V, d)), (HEAD_B, (V,))):
+            n = math.prod(shape)
+            self.layout.append((key, shape, off))
+            off += (n + 63) // 64 * 64
+        for i in reversed(range(geo.n_blocks)):
+            for name, fn in BLOCK_PARAM_SHAPES:
+                shape = fn(d, ff)
+                self.layout.append((block_key(i, name, geo.n_blocks), shape, off))
+                off += (math.prod(shape) + 63) // 64 * 64
+        self.numel = off
+        self.w = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device) if with_optimizer_state else None
+        self.v = torch.zeros(off, dtype=torch.float32, device=device) if with_optimizer_state else None
+        self.shadow = torch.zeros(off, dtype=compute_dtype, device=device) if compute_dtype != torch.float32 else self.w
+        self.offsets = {k: (o, s) for k, s, o in self.layout}
+
+    def view(self, buf: torch.Tensor, key: str) -> torch.Tensor:
+        o, shape = self.offsets[key]
+        return buf[o:o + math.prod(shape)].view(shape)
+
+    def param(self, key): return self.view(self.w, key)
+    def grad(self, key): return self.view(self.g, key)
+    def compute(self, key): return self.view(self.shadow, key)
+
+    def refresh_shadow(self):
+        if self.shadow is not self.w:
+            ops.cast(self.w, self.shadow)
+
+    def load(self, state: Dict[str, torch.Tensor]):
+        for key, shape, _ in self.layout:
+            self.param(key).copy_(state[key].to(self.w.device, torch.float32).reshape(shape))
+        self.refresh_shadow()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {key: self.param(key).clone() for key, _, _ in self.layout}
+
+
+class _Weights:
+    """Per-call view of the tensors the kernels read: matrices in compute dtype,
+    biases / LayerNorm affine in f32."""
+
+    def __init__(self, blocks, head_w, head_b):
+        self.blocks = blocks
+        self.head_w = head_w
+        self.head_b = head_b
+
+
+def weights_from_store(store: ParamStore) -> _Weights:
+    geo = store.geo
+    blocks = []
+    for i in range(geo.n_blocks):
+        b = {}
+        for name, _ in BLOCK_PARAM_SHAPES:
+            key = block_key(i, name, geo.n_blocks)
+            b[name] = store.compute(key) if name in MATRIX_KEYS else store.param(key)
+        blocks.append(b)
+    return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B))
+
+
+class DecoderEngine:
+    def __init__(self, geo: ModelGeometry, options: Optional[EngineOptions] = None):
+        self.geo = geo
+        self.opt = options or EngineOptions()
+        if geo.d_model % geo.nhead:
+            raise ValueError("d_model must be divisible by nhead")
+        if self.opt.mask_mode not in _MASKS:
+            raise ValueError(f"mask_mode must be one of {sorted(_MASKS)}")
+        if self.opt.activation not in _ACTS:
+            raise ValueError(f"activation must be one of {sorted(_ACTS)}")
+        _lib.load()
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self.cdt = self.opt.compute_dtype
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name: str, shape, dtype, device, zero: bool = False) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        key = (name, shape, dtype)
+        t = self._bufs.get(key)
+        if t is None or t.shape != shape or t.dtype != dtype or t.device != torch.device(device):
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = t
+            if zero:
+                t.zero_()
+        elif zero:
+            t.zero_()
+        return t
+
+    def _keys(self, site: int, step: int, train: bool):
+        p = self.geo.dropout if train else 0.0
+        return ops.dropout_keys(self.opt.dropout_seed, site, step, p)
+
+    # ------------------------------------------------------------------ one block, forward
+    def _block_fwd(self, i, W, x_in, B, S, q_start, train, step, dev, h1_ready=None):
+        """x_in [S*B,d] f32 -> rows q_start*B.. of the block output [Mt,d] f32.  Saves
+        what the backward needs in self.saved[i]."""
+        geo, cdt = self.geo, self.cdt
+        d, ff, H, hd = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd
+        M, r0 = S * B, q_start * B
+        Mt = M - r0
+        w = W.blocks[i]
+        sv = {}
+        if h1_ready is None:
+            h1 = self.buf(f"h1.{i}", (M, d), cdt, dev)
+            mean1 = self.buf(f"mean1.{i}", (M,), torch.float32, dev)
+            rstd1 = self.buf(f"rstd1.{i}", (M,), torch.float32, dev)
+            ops.ln_fwd(x_in, w["norm1.weight"], w["norm1.bias"], h1, mean1, rstd1)
+        else:
+            h1, mean1, rstd1 = h1_ready
+        qkv = self.buf(f"qkv.{i}", (M, 3 * d), cdt, dev)
+        scale = hd ** -0.5
+        in_w, in_b = w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"]
+        if q_start == 0:
+            ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d)
+        else:
+            ops.gemm(h1, in_w[d:], qkv[:, d:], bias=in_b[d:])
+            ops.gemm(h1[r0:], in_w[:d], qkv[r0:, :d], bias=in_b[:d], col_scale=scale, col_scale_n=d)
+        attn_o = self.buf(f"attn_o.{i}", (M, d), cdt, dev)
+        lse = self.buf(f"lse.{i}", (B * H * S,), torch.float32, dev)
+        k_attn = self._keys(4 * i + 0, step, train)
+        ops.attn_fwd_packed(qkv, attn_o, lse, B, H, S, hd, q_start=q_start, nq=S - q_start,
+                            mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn)
+        x_mid = self.buf(f"x_mid.{i}", (Mt, d), torch.float32, dev)
+        k_r1 = self._keys(4 * i + 1, step, train)
+        ops.gemm(attn_o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], drop=k_r1, residual=x_in[r0:])
+        h2 = self.buf(f"h2.{i}", (Mt, d), cdt, dev)
+        mean2 = self.buf(f"mean2.{i}", (Mt,), torch.float32, dev)
+        rstd2 = self.buf(f"rstd2.{i}", (Mt,), torch.float32, dev)
+        ops.ln_fwd(x_mid, w["norm2.weight"], w["norm2.bias"], h2, mean2, rstd2)
+        a1 = self.buf(f"a1.{i}", (Mt, ff), cdt, dev)
+        k_h = self._keys(4 * i + 2, step, train)
+        z1 = None
+        if self.opt.activation == "gelu" and train:
+            z1 = self.buf(f"z1.{i}", (Mt, ff), cdt, dev)
+        ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation], drop=k_h, aux_out=z1)
+        x_out = self.buf(f"x_out.{i}", (Mt, d), torch.float32, dev)
+        k_r2 = self._keys(4 * i + 3, step, train)
+        ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid)
+        sv.update(x_in=x_in, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x_mid=x_mid, h2=h2,
+                  mean2=mean2, rstd2=rstd2, a1=a1, z1=z1, q_start=q_start, keys=(k_attn, k_r1, k_h, k_r2))
+        self.saved[i] = sv
+        return x_out
+
+    # ------------------------------------------------------------------ forward to the scored rows
+    def forward_hidden(self, W: _Weights, source, *, L_scored: Optional[int], train: bool, step: int = 0, pos=None):
+        """source = ("concat", img, sos, cap) or ("tensor", tgt[S,B,d]).  Returns
+        (x [rows, d] f32 of the last block, first row index r0, B, S)."""
+        geo = self.geo
+        d = geo.d_model
+        if source[0] == "concat":
+            _, img, sos, cap = source
+            _lib.require_cuda(img, sos, cap)
+            B, P, _ = img.shape
+            S = P + 1 + cap.shape[1]
+            self.prefix_len = P
+        else:
+            tgt = source[1]
+            _lib.require_cuda(tgt)
+            S, B, _ = tgt.shape
+            self.prefix_len = source[2] if len(source) > 2 else 0
+        if self.opt.mask_mode == "prefix_causal" and self.prefix_len <= 0 and source[0] != "concat":
+            raise ValueError("prefix_causal masking needs the prefix length")
+        dev = source[1].device
+        M = S * B
+        self.saved = [None] * geo.n_blocks
+        nb = geo.n_blocks
+        last_q0 = (S - L_scored) if (L_scored is not None and self.opt.scored_rows_only) else 0
+        x = None
+        for i in range(nb):
+            q0 = last_q0 if i == nb - 1 else 0
+            if i == 0:
+                w0 = W.blocks[0]
+                h1 = self.buf("h1.0", (M, d), self.cdt, dev)
+                mean1 = self.buf("mean1.0", (M,), torch.float32, dev)
+                rstd1 = self.buf("rstd1.0", (M,), torch.float32, dev)
+                if source[0] == "concat":
+                    x0 = self.buf("x0", (M, d), torch.float32, dev)
+                    ops.concat_ln_fwd(img, sos, cap, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0, y_out=h1, mean=mean1, rstd=rstd1)
+                else:
+                    x0 = tgt.reshape(M, d)
+                    if x0.dtype != torch.float32 or not x0.is_contiguous():
+                        x0 = x0.float().contiguous()
+                    ops.ln_fwd(x0, w0["norm1.weight"], w0["norm1.bias"], h1, mean1, rstd1)
+                x = self._block_fwd(0, W, x0, B, S, q0, train, step, dev, h1_ready=(h1, mean1, rstd1))
+            else:
+                x = self._block_fwd(i, W, x, B, S, q0, train, step, dev)
+        self._shape = (B, S, last_q0)
+        return x, last_q0 * B, B, S
+
+    # ------------------------------------------------------------------ loss (+ optional backward into grads)
+    def loss_and_grads(self, W: _Weights, grads, source, labels, *, train: bool = True, step: int = 0, pos=None,
+                       want_grads: bool = True, grad_scale: float = 1.0, on_grad_ready=None, need_input_grad: bool = False):
+        """Mean cross-entropy over the B*L scored rows and the argmax-hit count
+        (decoder.py:172-185); with want_grads also d(loss*grad_scale)/d(params) written
+        into ``grads`` (name -> f32 tensor; block keys via block_key()).
+        Returns (loss_sum [1] f32, correct [1] int32, M) as DEVICE tensors: no host sync."""
+        geo, cdt = self.geo, self.cdt
+        d, V = geo.d_model, geo.vocab_size
+        _lib.require_cuda(labels)
+        Bl, L = labels.shape
+        x, r0, B, S = self.forward_hidden(W, source, L_scored=L, train=train, step=step, pos=pos)
+        assert Bl == B, "labels batch does not match inputs"
+        dev = labels.device
+        Mh = L * B
+        x_tail = x[x.shape[0] - Mh:]                           # scored rows (l*B + b)
+        h = self.buf("head_in", (Mh, d), cdt, dev)
+        ops.cast(x_tail, h) if cdt != torch.float32 else h.copy_(x_tail)
+        ws = self.buf("ce_ws", (ops.logits_ce_workspace(Mh, V),), torch.uint8, dev)
+        lse = self.buf("ce_lse", (Mh,), torch.float32, dev)
+        amax = self.buf("ce_argmax", (Mh,), torch.int32, dev)
+        loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        correct = torch.empty(1, dtype=torch.int32, device=dev)
+        ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws)
+        if not want_grads:
+            return loss_sum, correct, Mh
+        # ---- head backward, one vocabulary slab at a time: logits are never materialised
+        gscale = grad_scale / Mh
+        slab = min(self.opt.vocab_slab, (V + 127) // 128 * 128)
+        dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev)
+        dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
+        gW, gb = grads[HEAD_W], grads[HEAD_B]
+        gb.zero_()
+        first = True
+        for v0 in range(0, V, slab):
+            nv = min(slab, V - v0)
+            ld = (nv + 127) // 128 * 128
+            dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)
+            ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb)
+            ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first)
+            ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
+            first = False
+            if on_grad_ready is not None:
+                on_grad_ready(HEAD_W, v0, nv)
+        if on_grad_ready is not None:
+            on_grad_ready(HEAD_B, 0, V)
+        # ---- blocks backward
+        nb = geo.n_blocks
+        rows = x.shape[0]
+        if rows == Mh:
+            dx = dH
+        else:
+            dx = self.buf("dx_last", (rows, d), torch.float32, dev, zero=True)
+            dx[rows - Mh:].copy_(dH)
+        dx_input = None
+        for i in reversed(range(nb)):
+            need_dx_in = i > 0 or need_input_grad
+            dx = self._block_bwd(i, W, grads, dx, B, S, dev, need_dx_in)
+            if on_grad_ready is not None:
+                on_grad_ready(("block", i), 0, 0)
+        if need_input_grad:
+            dx_input = dx
+        self.input_grad = dx_input
+        return loss_sum, correct, Mh
+
+    # ------------------------------------------------------------------ one block, backward
+    def _block_bwd(self, i, W, grads, dx_out, B, S, dev, need_dx_in):
+        geo, cdt = self.geo, self.cdt
+        d, ff, H, hd = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd
+        nbk = geo.n_blocks
+        w, sv = W.blocks[i], self.saved[i]
+        q_start = sv["q_start"]
+        M, r0 = S * B, q_start * B
+        Mt = M - r0
+        k_attn, k_r1, k_h, k_r2 = sv["keys"]
+        G = lambda name: grads[block_key(i, name, nbk)]           # noqa: E731
+        for name in ("self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias", "linear2.bias"):
+            G(name).zero_()
+        # ---- MLP
+        g2 = self.buf("g_res", (Mt, d), cdt, dev)
+        ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"))
+        ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True)
+        dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
+        if self.opt.activation == "relu":
+            ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
+                     gate_drop=k_h, colsum=G("linear1.bias"))
+        else:
+            ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
+                     gate_drop=k_h, colsum=G("linear1.bias"))
+        ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
+        dh2 = self.buf("dh", (Mt, d), cdt, dev)
+        ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
+        dx_mid = self.buf(f"dx_mid", (Mt, d), torch.float32, dev)
+        lnws = self.buf("ln_ws", (ops.ln_bwd_workspace(M, d),), torch.uint8, dev)
+        ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
+        # ---- attention
+        g1 = g2
+        ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"))
+        ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
+        dattn = self.buf("dattn", (M, d), cdt, dev)
+        ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
+        dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
+        delta = self.buf("delta", (B * H * S,), torch.float32, dev)
+        ops.attn_bwd_packed(sv["qkv"], sv["attn_o"], sv["lse"], dattn, dqkv, delta, B, H, S, hd, q_start=q_start, nq=S - q_start,
+                            mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5)
+        gin_w, gin_b = G("self_attn.in_proj_weight"), G("self_attn.in_proj_bias")
+        h1 = sv["h1"]
+        if q_start == 0:
+            ops.colsum(dqkv, gin_b)
+            ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True)
+        else:
+            ops.colsum(dqkv[r0:, :d], gin_b[:d])
+            ops.colsum(dqkv[:, d:], gin_b[d:])
+            ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
+            ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True)
+        # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
+        in_w = w["self_attn.in_proj_weight"]
+        dh1 = self.buf("dh1", (M, d), torch.float32, dev)
+        if q_start == 0:
+            ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
+        else:
+            ops.gemm(dqkv[:, d:], in_w[d:], dh1, M=M, N=d, K=2 * d, b_kmajor=True)
+            ops.gemm(dqkv[r0:, :d], in_w[:d], dh1[r0:], M=Mt, N=d, K=d, b_kmajor=True, accumulate=True)
+        if q_start == 0:
+            dres = dx_mid
+        else:
+            dres = self.buf("dres", (M, d), torch.float32, dev, zero=True)
+            dres[r0:].copy_(dx_mid)
+        dx_in = self.buf(f"dx_in.{i % 2}", (M, d), torch.float32, dev)
+        ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
+        return dx_in
+
+    # ------------------------------------------------------------------ all-rows logits (the reference's forward)
+    def forward_logits(self, W: _Weights, source, *, train: bool, step: int = 0, pos=None) -> torch.Tensor:
+        """decoder.py:40-68: logits [S,B,V] f32 for ALL rows (compatibility path)."""
+        x, r0, B, S = self.forward_hidden(W, source, L_scored=None, train=train, step=step, pos=pos)
+        dev = x.device
+        d, V = self.geo.d_model, self.geo.vocab_size
+        h = self.buf("all_in", (S * B, d), self.cdt, dev)
+        ops.cast(x, h) if self.cdt != torch.float32 else h.copy_(x)
+        out = torch.empty(S * B, V, dtype=torch.float32, device=dev)
+        ops.gemm(h, W.head_w, out, bias=W.head_b)
+        self._all_in = h
+        return out.view(S, B, V)
+
+    def backward_logits(self, W: _Weights, grads, dlogits: torch.Tensor, need_input_grad: bool = False):
+        """Backward of forward_logits given d(loss)/d(logits) [S,B,V]."""
+        geo, cdt = self.geo, self.cdt
+        d, V = geo.d_model, geo.vocab_size
+        B, S, _ = self._shape
+        dev = dlogits.device
+        M = S * B
+        Vp = (V + 7) // 8 * 8
+        dl = self.buf("dl_all", (M, Vp), cdt, dev, zero=True)
+        dl[:, :V].copy_(dlogits.reshape(M, V))
+        h = self._all_in
+        grads[HEAD_B].zero_()
+        ops.colsum(dl[:, :V], grads[HEAD_B])
+        ops.gemm(dl, h, grads[HEAD_W], M=V, N=d, K=M, a_kmajor=True, b_kmajor=True)
+        dx = self.buf("dx_all", (M, d), torch.float32, dev)
+        ops.gemm(dl, W.head_w, dx, M=M, N=d, K=V, b_kmajor=True)
+        for i in reversed(range(geo.n_blocks)):
+            dx = self._block_bwd(i, W, grads, dx, B, S, dev, i > 0 or need_input_grad)
+        self.input_grad = dx if need_input_grad else None
+
+    # ------------------------------------------------------------------ KV-cached greedy decoding
+    @torch.no_grad()
+    def generate(self, W: _Weights, img, sos_slot, emb, *, max_len: int, sos_id: int, eos_id: int, pad_id: int,
+                 pos=None, return_margins: bool = False):
+        """Greedy captions for a batch of image prefixes.  seq0 = [img | sos_slot | E[sos]];
+        step t scores the last row, appends E[argmax].  K/V of every row are computed
+        once and cached ([B,H,2,S,hd] per block).  Returns ids [B,max_len] int64."""
+        geo, cdt = self.geo, self.cdt
+        d, ff, H, hd, V, nb = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd, geo.vocab_size, geo.n_blocks
+        _lib.require_cuda(img, sos_slot, emb)
+        if nb > 1 and self.opt.mask_mode != "prefix_causal":
+            raise ValueError("KV-cached decoding with stacked blocks is only exact under mask_mode='prefix_causal'")
+        B, P, _ = img.shape
+        dev = img.device
+        S0, smax = P + 2, P + 1 + max_len
+        mask = _MASKS[self.opt.mask_mode]
+        scale = hd ** -0.5
+        caches = [self.buf(f"kv.{i}", (B, H, 2, smax, hd), cdt, dev) for i in range(nb)]
+        ids = torch.full((B,), sos_id, dtype=torch.int64, device=dev)
+        first = self.buf("gen_first", (B, 1, d), torch.float32, dev)
+        ops.embed_rows(emb, ids, first.view(B, d))
+        # ---- prefill: all P+2 rows through every block (last block: only the last row's query)
+        M0 = S0 * B
+        x = self.buf("gen_x0", (M0, d), torch.float32, dev)
+        h1 = self.buf("gen_h1", (M0, d), cdt, dev)
+        w0 = W.blocks[0]
+        ops.concat_ln_fwd(img, sos_slot, first.to(img.dtype), w0["norm1.weight"], w0["norm1.bias"],
+                          pos=pos[:S0].contiguous() if pos is not None else None, x_out=x, y_out=h1)
+        kvs = (H * 2 * smax * hd, 2 * smax * hd, hd)
+        for i in range(nb):
+            w = W.blocks[i]
+            last = i == nb - 1
+            q0 = S0 - 1 if last else 0
+            r0 = q0 * B
+            if i > 0:
+                ops.ln_fwd(x, w["norm1.weight"], w["norm1.bias"], h1)
+            q = self.buf("gen_q", (M0, d), cdt, dev)
+            # K/V of all rows straight into the cache; q rows only where needed
+            in_w, in_b = w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"]
+            if q0 == 0:
+                ops.gemm(h1, in_w, q, bias=in_b, col_scale=scale, col_scale_n=d, kv_cache=caches[i], kv_geom=(d, d, B, H, hd, smax, 0))
+            else:
+                ops.gemm(h1, in_w[d:], q, bias=in_b[d:], kv_cache=caches[i], kv_geom=(0, d, B, H, hd, smax, 0))
+                ops.gemm(h1[r0:], in_w[:d], q[r0:], bias=in_b[:d], col_scale=scale, col_scale_n=d)
+            o = self.buf("gen_o", (M0, d), cdt, dev)
+            desc_strides = ((d, hd, B * d), kvs, kvs, (d, hd, B * d))
+            self._attn_cache_fwd(q, caches[i], o, desc_strides, B, H, S0, hd, smax, q0, S0 - q0, mask, P)
+            Mt = M0 - r0
+            x_mid = self.buf("gen_xmid", (Mt, d), torch.float32, dev)
+            ops.gemm(o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], residual=x[r0:])
+            h2 = self.buf("gen_h2", (Mt, d), cdt, dev)
+            ops.ln_fwd(x_mid, w["norm2.weight"], w["norm2.bias"], h2)
+            a1 = self.buf("gen_a1", (Mt, ff), cdt, dev)
+            ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation])
+            x_next = self.buf(f"gen_xout.{i % 2}", (Mt, d), torch.float32, dev)
+            ops.gemm(a1, w["linear2.weight"], x_next, bias=w["linear2.bias"], residual=x_mid)
+            x = x_next
+        x_last = x[x.shape[0] - B:]                                 # [B,d] hidden of the newest row
+        # ---- decode loop
+        out = torch.full((B, max_len), pad_id, dtype=torch.int64, device=dev)
+        margins = torch.zeros(B, max_len, dtype=torch.float32, device=dev) if return_margins else None
+        done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        ws = self.buf("gen_ws", (ops.logits_ce_workspace(B, V),), torch.uint8, dev)
+        hh = self.buf("gen_hh", (B, d), cdt, dev)
+        mg = self.buf("gen_margin", (B,), torch.float32, dev)
+        xs = self.buf("gen_xs", (B, d), torch.float32, dev)
+        hs = self.buf("gen_hs", (B, d), cdt, dev)
+        qs = self.buf("gen_qs", (B, d), cdt, dev)
+        os_ = self.buf("gen_os", (B, d), cdt, dev)
+        xm = self.buf("gen_xm", (B, d), torch.float32, dev)
+        h2s = self.buf("gen_h2s", (B, d), cdt, dev)
+        a1s = self.buf("gen_a1s", (B, ff), cdt, dev)
+        xo = [self.buf(f"gen_xo{j}", (B, d), torch.float32, dev) for j in range(2)]
+        for t in range(max_len):
+            ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
+            ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg, ws)
+            if return_margins:
+                margins[:, t].copy_(mg)
+            ops.greedy_update(ids, done, out, t, eos_id, pad_id)
+            if t + 1 == max_len:
+                break
+            s_new = S0 + t                                           # index of the appended row
+            ops.embed_rows(emb, ids, xs, pos_row=pos[s_new].contiguous() if pos is not None else None)
+            xcur = xs
+            for i in range(nb):
+                w = W.blocks[i]
+                ops.ln_fwd(xcur, w["norm1.weight"], w["norm1.bias"], hs)
+                ops.gemm(hs, w["self_attn.in_proj_weight"], qs, bias=w["self_attn.in_proj_bias"], col_scale=scale, col_scale_n=d,
+                         kv_cache=caches[i], kv_geom=(d, d, B, H, hd, smax, s_new))
+                ops.attn_decode(qs, caches[i], os_, B, H, hd, smax, s_new + 1)
+                ops.gemm(os_, w["self_attn.out_proj.weight"], xm, bias=w["self_attn.out_proj.bias"], residual=xcur)
+                ops.ln_fwd(xm, w["norm2.weight"], w["norm2.bias"], h2s)
+                ops.gemm(h2s, w["linear1.weight"], a1s, bias=w["linear1.bias"], act=_ACTS[self.opt.activation])
+                ops.gemm(a1s, w["linear2.weight"], xo[i % 2], bias=w["linear2.bias"], residual=xm)
+                xcur = xo[i % 2]
+            x_last = xcur
+        return (out, margins) if return_margins else out
+
+    def _attn_cache_fwd(self, q, cache, o, strides, B, H, S, hd, smax, q_start, nq, mask, prefix):
+        import ctypes as C
+        from ._lib import AttnDesc, check, ptr, stream_ptr
+        desc = AttnDesc()
+        kbase = cache
+        vbase = cache.view(-1)[smax * hd:]
+        ops._fill_attn(desc, q, kbase, vbase, o, strides, B, H, S, hd, q_start, nq, mask, prefix, _lib.NO_DROPOUT, None)
+        check(_lib.load().capdec_attn_fwd(C.byref(desc), stream_ptr()), "capdec_attn_fwd")

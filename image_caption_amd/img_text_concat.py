@@ -1,0 +1,55 @@
+"""The prefix-join step of the reference's img_text_concat.py, on the GPU.
+
+``process_batch`` keeps the reference's output contract (img_text_concat.py:130-134):
+
+    {'decoder_inputs':   [S, B, d] float, rows = P patches | 1 <sos> slot | L caption rows,
+     'caption_input_ids': [B, L] int64,
+     'caption_labels':    [B, L] int64}
+
+with S = P + 1 + L (img_text_concat.py:98-99) and the three shape checks of
+img_text_concat.py:126-128.  What differs is the INPUT: the reference computes the
+embeddings from PIL images and strings with frozen ViT / GPT-2 encoders
+(img_text_concat.py:32-65), which are outside this package; here the batch
+carries the embeddings themselves.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import config
+
+# the reference repeats config.max_caption_length as a module constant (img_text_concat.py:30)
+max_caption_length = 32
+
+
+def join_prefix(image_embeddings: torch.Tensor, sos_embedding: torch.Tensor, caption_embeddings: torch.Tensor,
+                pos: torch.Tensor = None) -> torch.Tensor:
+    """cat([img, sos, cap], dim=1).transpose(0, 1) (img_text_concat.py:115-123) as one
+    gather kernel: [B,P,d] + [B,1,d] + [B,L,d] -> [P+1+L, B, d] float32, contiguous."""
+    B, P, d = image_embeddings.shape
+    L = caption_embeddings.shape[1]
+    S = P + 1 + L
+    out = torch.empty(S * B, d, dtype=torch.float32, device=image_embeddings.device)
+    ops.concat_ln_fwd(image_embeddings.contiguous(), sos_embedding.contiguous(), caption_embeddings.contiguous(),
+                      None, None, pos=pos, x_out=out)
+    return out.view(S, B, d)
+
+
+def process_batch(batch):
+    """batch = {'image_embeddings': [B,P,d], 'sos_embedding': [B,1,d],
+    'caption_embeddings': [B,L,d], 'caption_input_ids': [B,L], 'caption_labels': [B,L]}."""
+    image_embeddings = batch["image_embeddings"]
+    sos_embedding = batch["sos_embedding"]
+    caption_embeddings = batch["caption_embeddings"]
+    batch_size = image_embeddings.size(0)
+    seq_len = image_embeddings.size(1) + 1 + caption_embeddings.size(1)
+    decoder_inputs = join_prefix(image_embeddings, sos_embedding, caption_embeddings)
+    assert decoder_inputs.size(0) == seq_len, f"Sequence length mismatch: {decoder_inputs.size(0)} != {seq_len}"
+    assert decoder_inputs.size(1) == batch_size, f"Batch size mismatch: {decoder_inputs.size(1)} != {batch_size}"
+    assert decoder_inputs.size(2) == image_embeddings.size(2), "Embedding dimension mismatch"
+    return {
+        "decoder_inputs": decoder_inputs,
+        "caption_input_ids": batch["caption_input_ids"],
+        "caption_labels": batch["caption_labels"],
+    }

@@ -32,12 +32,13 @@ def dropout_keys(seed: int, site: int, step: int = 0, p: float = 0.0) -> Dropout
 
 def dropout_mask(d: Dropout, n: int, device) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.float32, device=device)
+    require_cuda(out)
     check(_lib.load().capdec_dropout_mask(d, n, ptr(out), _st()), "capdec_dropout_mask")
     return out
 
 
 def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None, y_out=None, mean=None, rstd=None):
-    require_cuda(img, sos, cap)
+    require_cuda(img, sos, cap, pos, gamma, beta, x_out, y_out, mean, rstd)
     B, P, d = img.shape
     L = cap.shape[1]
     assert sos.shape == (B, 1, d) and cap.shape == (B, L, d)
@@ -50,6 +51,7 @@ def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None,
 
 
 def ln_fwd(x, gamma, beta, y_out, mean=None, rstd=None, eps=1e-5):
+    require_cuda(x, gamma, beta, y_out)
     M, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and y_out.is_contiguous()
     check(_lib.load().capdec_ln_fwd(ptr(x), ptr(gamma), ptr(beta), eps, M, d, ptr(y_out), dtype_code(y_out), ptr(mean), ptr(rstd), _st()),
@@ -61,6 +63,7 @@ def ln_bwd_workspace(M, d) -> int:
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx_out, dgamma, dbeta, partial):
+    require_cuda(dy, x, gamma, mean, rstd, dx_out, dgamma, dbeta, partial)
     M, d = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dx_out.is_contiguous()
     check(_lib.load().capdec_ln_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), M, d,
@@ -77,7 +80,7 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
          gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
     B is [N,K] (or [K,N] if b_kmajor)."""
-    require_cuda(A, B, Cout)
+    require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache)
     assert A.dtype == B.dtype
     if M is None:
         M = A.shape[1] if a_kmajor else A.shape[0]
@@ -106,14 +109,15 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
         d.aux_out, d.ldaux = ptr(aux_out), _ld(aux_out)
     d.colsum = ptr(colsum)
     if kv_cache is not None:
-        dm, Bk, H, hd, smax, s0 = kv_geom
+        qcols, dm, Bk, H, hd, smax, s0 = kv_geom
         assert kv_cache.dtype == Cout.dtype
-        d.kv_cache, d.kv_d, d.kv_B, d.kv_H, d.kv_hd, d.kv_smax, d.kv_s0 = ptr(kv_cache), dm, Bk, H, hd, smax, s0
+        d.kv_cache, d.kv_q, d.kv_d, d.kv_B, d.kv_H, d.kv_hd, d.kv_smax, d.kv_s0 = ptr(kv_cache), qcols, dm, Bk, H, hd, smax, s0
     check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
     return Cout
 
 
 def _fill_attn(desc: AttnDesc, q, k, v, o, strides, B, H, S, hd, q_start, nq, mask_mode, prefix_len, drop, lse):
+    require_cuda(q, k, v, o, lse)
     desc.q, desc.k, desc.v, desc.o = ptr(q), ptr(k), ptr(v), ptr(o)
     (desc.q_bs, desc.q_hs, desc.q_ss), (desc.k_bs, desc.k_hs, desc.k_ss), (desc.v_bs, desc.v_hs, desc.v_ss), \
         (desc.o_bs, desc.o_hs, desc.o_ss) = strides
@@ -158,6 +162,7 @@ def attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, *, q_start=0, n
 
 
 def attn_decode(q, kv_cache, o, B, H, hd, smax, length):
+    require_cuda(q, kv_cache, o)
     check(_lib.load().capdec_attn_decode(ptr(q), ptr(kv_cache), ptr(o), dtype_code(q), B, H, hd, smax, length, _st()),
           "capdec_attn_decode")
 
@@ -167,6 +172,7 @@ def logits_ce_workspace(M, V) -> int:
 
 
 def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace):
+    require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace)
     M, d = h.shape
     V = W.shape[0]
     assert labels.dtype == torch.int64 and labels.is_contiguous()
@@ -176,6 +182,7 @@ def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, work
 
 
 def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias):
+    require_cuda(h, W, bias, labels, lse, dl, dbias)
     M, d = h.shape
     V = W.shape[0]
     check(_lib.load().capdec_logits_ce_bwd_slab(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
@@ -184,6 +191,7 @@ def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias)
 
 
 def logits_argmax(h, W, bias, out_ids, margin, workspace):
+    require_cuda(h, W, bias, out_ids, margin, workspace)
     M, d = h.shape
     V = W.shape[0]
     check(_lib.load().capdec_logits_argmax(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(out_ids), ptr(margin),
@@ -191,32 +199,38 @@ def logits_argmax(h, W, bias, out_ids, margin, workspace):
 
 
 def cast(src, dst):
+    require_cuda(src, dst)
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     check(_lib.load().capdec_cast(ptr(src), dtype_code(src), ptr(dst), dtype_code(dst), src.numel(), _st()), "capdec_cast")
     return dst
 
 
 def dropout_bwd_cast(dx, drop: Dropout, g, colsum=None):
+    require_cuda(dx, g, colsum)
     M, N = dx.shape
     assert dx.dtype == torch.float32 and dx.is_contiguous() and g.is_contiguous()
     check(_lib.load().capdec_dropout_bwd_cast(ptr(dx), M, N, drop, ptr(g), dtype_code(g), ptr(colsum), _st()), "capdec_dropout_bwd_cast")
 
 
 def colsum(x, out):
+    require_cuda(x, out)
     M, N = x.shape
     check(_lib.load().capdec_colsum(ptr(x), dtype_code(x), M, N, _ld(x), ptr(out), _st()), "capdec_colsum")
 
 
 def embed_rows(table, ids, out, pos_row=None):
+    require_cuda(table, ids, out, pos_row)
     n, d = out.shape
     check(_lib.load().capdec_embed_rows(ptr(table), ptr(ids), n, d, ptr(pos_row), ptr(out), _st()), "capdec_embed_rows")
 
 
 def adam_step(w, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, w_bf16=None):
+    require_cuda(w, g, m, v, w_bf16)
     check(_lib.load().capdec_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), step, lr, beta1, beta2, eps, weight_decay,
                                        grad_scale, ptr(w_bf16), _st()), "capdec_adam_step")
 
 
 def greedy_update(ids, done, out, t, eos_id, pad_id):
+    require_cuda(ids, done, out)
     B, L = out.shape
     check(_lib.load().capdec_greedy_update(ptr(ids), ptr(done), ptr(out), B, L, t, eos_id, pad_id, _st()), "capdec_greedy_update")

@@ -107,9 +107,9 @@ typedef struct {
     const void* gate; long ldg; int gate_mode; int gate_dtype; capdec_dropout gate_drop;
     void* aux_out; long ldaux;   /* out_dtype, NULL = off */
     float* colsum;               /* [N] f32 atomically += column sums of the stored values */
-    /* K/V-cache scatter (greedy decoding): columns >= kv_d go to
-     * kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_d go to C. */
-    void* kv_cache; int kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
+    /* K/V-cache scatter (greedy decoding): columns >= kv_q (kv_q = 0 or kv_d; N = kv_q + 2*kv_d)
+     * go to kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_q go to C. */
+    void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);

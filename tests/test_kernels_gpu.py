@@ -103,12 +103,17 @@ def test_gemm_kv_scatter(dtype):
     W = rnd(3 * d, 64, dtype=dtype, scale=0.2, seed=13)
     qout = torch.zeros(M, d, device=DEV, dtype=dtype)
     cache = torch.zeros(Bb, H, 2, smax, hd, device=DEV, dtype=dtype)
-    ops.gemm(x, W, qout, col_scale=0.25, col_scale_n=d, kv_cache=cache, kv_geom=(d, Bb, H, hd, smax, s0))
+    ops.gemm(x, W, qout, col_scale=0.25, col_scale_n=d, kv_cache=cache, kv_geom=(d, d, Bb, H, hd, smax, s0))
     y = x.float() @ W.float().t()
     close(qout, y[:, :d] * 0.25, 1.5e-2, "q")
     kv = y[:, d:].reshape(ns, Bb, 2, H, hd).permute(1, 3, 2, 0, 4)          # [B,H,2,ns,hd]
     close(cache[:, :, :, s0:s0 + ns], kv, 1.5e-2, "kv")
     assert cache[:, :, :, :s0].abs().max().item() == 0 and cache[:, :, :, s0 + ns:].abs().max().item() == 0
+    # K/V columns only (no query columns)
+    cache2 = torch.zeros_like(cache)
+    dummy = torch.zeros(M, 2 * d, device=DEV, dtype=dtype)
+    ops.gemm(x, W[d:], dummy, kv_cache=cache2, kv_geom=(0, d, Bb, H, hd, smax, s0))
+    assert torch.equal(cache2, cache)
 
 
 # ---------------------------------------------------------------------------- LayerNorm / concat

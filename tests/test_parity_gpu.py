@@ -1,0 +1,375 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in module) with
+  (a) golden vectors recorded from the reference's own TransformerDecoder, and
+  (b) the CPU oracle on the same seeded inputs.
+
+Stated tolerances:
+  f32 validation mode : logits <= 1e-4 abs, loss <= 1e-5 rel, grads <= 1e-4 of the
+                        tensor's max, greedy ids identical.
+  bf16 MFMA mode      : logits <= 5e-2 abs (logit scale ~3), loss <= 1e-2 rel,
+                        gradient cosine >= 0.999 per tensor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers  # noqa: E402
+from helpers import DEFAULT_B8, GOLDEN_DIR, TINY  # noqa: E402
+from image_caption_amd import ops  # noqa: E402
+from image_caption_amd.decoder import CaptionTrainer, TransformerDecoder  # noqa: E402
+from image_caption_amd.engine import EngineOptions, block_key  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+DEV = "cuda"
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def make_model(sh, sd, dtype, dropout=0.0, n_blocks=1, **opt):
+    m = TransformerDecoder(sh.d, sh.nhead, 6, sh.ff, dropout, sh.vocab, n_blocks=n_blocks,
+                           options=EngineOptions(compute_dtype=dtype, **opt))
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def check_grads(model, ref_grads, dtype):
+    for k, ref in ref_grads.items():
+        g = dict(model.named_parameters())[k].grad.cpu()
+        ref = torch.as_tensor(ref)
+        if dtype == F32:
+            assert (g - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-9, k
+        else:
+            assert cos(g, ref) >= 0.999, (k, cos(g, ref))
+
+
+# ---------------------------------------------------------------------------- golden: tiny, full tensors
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_tiny_golden_logits_loss_grads(dtype):
+    g = golden("tiny.npz")
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=101)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=202)
+    model = make_model(sh, sd, dtype)
+    model.train()
+    x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
+    # (1) the reference's forward: logits for all rows
+    logits = model(x, x)
+    tol = 1e-4 if dtype == F32 else 5e-2
+    assert (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() <= tol
+    # (2) the reference's step body on those logits (decoder.py:172-190)
+    capo = logits[-sh.L:].permute(1, 0, 2)
+    loss = torch.nn.CrossEntropyLoss()(capo.reshape(-1, sh.vocab), labels.to(DEV).reshape(-1))
+    assert abs(loss.item() - float(g["loss"])) <= (1e-5 if dtype == F32 else 1e-2) * float(g["loss"])
+    loss.backward()
+    ref_grads = {k: g["grad." + k] for k in ref_cpu.PARAM_KEYS}
+    check_grads(model, ref_grads, dtype)
+    # (3) the fused path: join + scored rows only, logits never materialised
+    model.zero_grad()
+    loss2, correct = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    assert abs(loss2.item() - float(g["loss"])) <= (1e-5 if dtype == F32 else 1e-2) * float(g["loss"])
+    if dtype == F32:
+        assert int(correct.item()) == int(g["correct"])
+    loss2.backward()
+    check_grads(model, ref_grads, dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_default_b8_golden(dtype):
+    g = golden("default_b8.npz")
+    sh = DEFAULT_B8
+    sd = helpers.make_state_dict(sh, seed=303)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=404)
+    model = make_model(sh, sd, dtype)
+    x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
+    with torch.no_grad():
+        logits = model(x, x)
+    tol = 1e-4 if dtype == F32 else 5e-2
+    assert (logits[-sh.L:, :, ::997].cpu() - torch.from_numpy(g["logits_tail_strided"])).abs().max().item() <= tol
+    assert (logits[0, :, ::997].cpu() - torch.from_numpy(g["logits_row0_strided"])).abs().max().item() <= tol
+    del logits
+    loss, correct = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    assert abs(loss.item() - float(g["loss"])) <= (1e-5 if dtype == F32 else 1e-2) * float(g["loss"])
+    if dtype == F32:
+        assert int(correct.item()) == int(g["correct"])
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in ref_cpu.PARAM_KEYS:
+        gn = named[k].grad.norm().item()
+        ref = float(g["gnorm." + k])
+        assert abs(gn - ref) <= (2e-4 if dtype == F32 else 2e-2) * ref, (k, gn, ref)
+    rows = named["output_projection.weight"].grad[::1009].cpu()
+    ref_rows = torch.from_numpy(g["grad.output_projection.weight_rows"])
+    if dtype == F32:
+        assert (rows - ref_rows).abs().max().item() <= 1e-4 * ref_rows.abs().max().item()
+        assert (named["norm2.weight"].grad.cpu() - torch.from_numpy(g["grad.norm2.weight"])).abs().max().item() <= \
+            1e-4 * np.abs(g["grad.norm2.weight"]).max()
+    else:
+        assert cos(rows, ref_rows) >= 0.999
+        assert cos(named["self_attn.in_proj_bias"].grad.cpu(), torch.from_numpy(g["grad.self_attn.in_proj_bias"])) >= 0.999
+
+
+# ---------------------------------------------------------------------------- oracle: build-defined modes
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mask_mode,activation,n_blocks,use_pos,scored", [
+    ("reference", "relu", 1, False, False),
+    ("prefix_causal", "relu", 1, False, True),
+    ("prefix_causal", "gelu", 2, True, True),
+    ("none", "gelu", 3, False, True),
+])
+def test_modes_vs_oracle(dtype, mask_mode, activation, n_blocks, use_pos, scored):
+    sh = TINY
+    sds = [helpers.make_state_dict(sh, seed=900 + i) for i in range(n_blocks)]
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=606)
+    pos = 0.3 * torch.randn(sh.S, sh.d, generator=torch.Generator().manual_seed(5)) if use_pos else None
+    # product model: block 0 = reference keys, further blocks under blocks.{i}.
+    full = dict(sds[0])
+    for i in range(1, n_blocks):
+        for k in ref_cpu.BLOCK_KEYS:
+            full[block_key(i, k, n_blocks)] = sds[i][k]
+    model = make_model(sh, full, dtype, n_blocks=n_blocks, mask_mode=mask_mode, activation=activation, scored_rows_only=scored)
+    model.train()
+    loss, correct = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV),
+                                       pos=pos.to(DEV) if use_pos else None)
+    loss.backward()
+    # oracle
+    leaf = [{k: sds[i][k].clone().requires_grad_(True) for k in ref_cpu.BLOCK_KEYS} for i in range(n_blocks)]
+    head = {k: sds[0][k].clone().requires_grad_(True) for k in ref_cpu.PARAM_KEYS[12:]}
+    x = ref_cpu.concat_prefix(img, sos, cap, pos)
+    lg = ref_cpu.decoder_forward(x, leaf, head, sh.nhead, mask_mode=mask_mode, prefix_len=sh.P, activation=activation)
+    lo, co, _ = ref_cpu.caption_loss(lg, labels, sh.L)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= (1e-5 if dtype == F32 else 1e-2) * lo.item()
+    if dtype == F32:
+        assert int(correct.item()) == co
+    ref_grads = {k: head[k].grad for k in head}
+    for i in range(n_blocks):
+        for k in ref_cpu.BLOCK_KEYS:
+            ref_grads[block_key(i, k, n_blocks)] = leaf[i][k].grad
+    check_grads(model, ref_grads, dtype)
+
+
+def test_composed_golden():
+    """prefix-causal and stacked blocks against vectors produced by composing the reference class."""
+    g = golden("composed.npz")
+    sh = TINY
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=606)
+    x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
+    m = make_model(sh, helpers.make_state_dict(sh, seed=505), F32, mask_mode="prefix_causal")
+    m.prefix_len = sh.P
+    with torch.no_grad():
+        lg = m(x, x)
+    assert (lg.cpu() - torch.from_numpy(g["prefix_causal_logits"])).abs().max().item() <= 1e-4
+    sa, sb = helpers.make_state_dict(sh, seed=707), helpers.make_state_dict(sh, seed=808)
+    full = dict(sa)
+    full.update({k: sb[k] for k in ref_cpu.PARAM_KEYS[12:]})
+    for k in ref_cpu.BLOCK_KEYS:
+        full[block_key(1, k, 2)] = sb[k]
+    m2 = make_model(sh, full, F32, n_blocks=2)
+    with torch.no_grad():
+        lg2 = m2(x, x)
+    assert (lg2.cpu() - torch.from_numpy(g["two_block_logits"])).abs().max().item() <= 1e-4
+    m3 = make_model(sh, full, F32, n_blocks=2, mask_mode="prefix_causal")
+    loss, _ = m3.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    assert abs(loss.item() - float(g["two_block_pc_loss"])) <= 1e-5 * float(g["two_block_pc_loss"])
+    loss.backward()
+    named = dict(m3.named_parameters())
+    ga = torch.from_numpy(g["two_block_pc_grad_a_linear1_weight"])
+    gb = torch.from_numpy(g["two_block_pc_grad_b_in_proj_weight"])
+    assert (named["linear1.weight"].grad.cpu() - ga).abs().max().item() <= 1e-4 * ga.abs().max().item()
+    assert (named["blocks.1.self_attn.in_proj_weight"].grad.cpu() - gb).abs().max().item() <= 1e-4 * gb.abs().max().item()
+
+
+# ---------------------------------------------------------------------------- dropout: same masks handed to the oracle
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_training_dropout_vs_oracle_with_same_masks(dtype):
+    sh = TINY
+    p = 0.2
+    sd = helpers.make_state_dict(sh, seed=111)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=222)
+    model = make_model(sh, sd, dtype, dropout=p, scored_rows_only=False)
+    model.train()
+    loss, _ = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    loss.backward()
+    step = model._step
+    seed = model.options.dropout_seed
+    S, B, d, ff, H = sh.S, sh.B, sh.d, sh.ff, sh.nhead
+    keep = {
+        "attn": ops.dropout_mask(ops.dropout_keys(seed, 0, step, p), B * H * S * S, DEV).reshape(B, H, S, S).cpu(),
+        "resid1": ops.dropout_mask(ops.dropout_keys(seed, 1, step, p), S * B * d, DEV).reshape(S, B, d).cpu(),
+        "hidden": ops.dropout_mask(ops.dropout_keys(seed, 2, step, p), S * B * ff, DEV).reshape(S, B, ff).cpu(),
+        "resid2": ops.dropout_mask(ops.dropout_keys(seed, 3, step, p), S * B * d, DEV).reshape(S, B, d).cpu(),
+    }
+    for v in keep.values():
+        assert 0.7 < v.mean().item() < 0.9
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    blocks, head = ref_cpu.split_params(leaf)
+    x = ref_cpu.concat_prefix(img, sos, cap)
+    lg = ref_cpu.decoder_forward(x, blocks, head, sh.nhead, drop_p=p, keep=[keep])
+    lo, _, _ = ref_cpu.caption_loss(lg, labels, sh.L)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= (2e-5 if dtype == F32 else 1e-2) * lo.item()
+    check_grads(model, {k: leaf[k].grad for k in leaf}, dtype)
+    # evaluation mode ignores dropout
+    model.eval()
+    with torch.no_grad():
+        le, _ = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    lg0 = ref_cpu.decoder_forward(x, *ref_cpu.split_params(sd), sh.nhead)
+    l0, _, _ = ref_cpu.caption_loss(lg0, labels, sh.L)
+    assert abs(le.item() - l0.item()) <= (2e-5 if dtype == F32 else 1e-2) * l0.item()
+
+
+def test_scored_rows_only_is_exact():
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=121)
+    img, sos, cap, labels = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=232)]
+    outs = []
+    for scored in (False, True):
+        m = make_model(sh, sd, F32, scored_rows_only=scored)
+        loss, correct = m.caption_loss((img, sos, cap), labels)
+        loss.backward()
+        outs.append((loss.item(), correct.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]) and outs[0][1] == outs[1][1]
+    for k in outs[0][2]:
+        a, b = outs[0][2][k], outs[1][2][k]
+        assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-10, k
+
+
+# ---------------------------------------------------------------------------- Adam / trainer
+def test_trainer_two_adam_steps_match_reference():
+    g = golden("tiny.npz")
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=101)
+    img, sos, cap, labels = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=202)]
+    model = make_model(sh, sd, F32)
+    model.train()
+    tr = CaptionTrainer(model, lr=1e-4, weight_decay=0.01)
+    l1, _, rows = tr.step((img, sos, cap), labels)
+    l2, _, _ = tr.step((img, sos, cap), labels)
+    assert abs(l1.item() / rows - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert abs(l2.item() / rows - float(g["loss_step2"])) <= 1e-5 * float(g["loss_step2"])
+    state = model.state_dict()
+    for k in ref_cpu.PARAM_KEYS:
+        assert (state[k].cpu() - torch.from_numpy(g["after2." + k])).abs().max().item() <= 3e-6, k
+
+
+def test_trainer_bf16_loss_decreases_and_tracks_f32():
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=131)
+    img, sos, cap, labels = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=242)]
+    losses = {}
+    for dtype in (F32, BF16):
+        model = make_model(sh, sd, dtype)
+        tr = CaptionTrainer(model, lr=1e-3, weight_decay=0.01)
+        losses[dtype] = [tr.step((img, sos, cap), labels)[0].item() / (sh.B * sh.L) for _ in range(8)]
+    assert losses[BF16][-1] < losses[BF16][0]
+    for a, b in zip(losses[F32], losses[BF16]):
+        assert abs(a - b) <= 1e-2 * a
+
+
+# ---------------------------------------------------------------------------- greedy decoding
+@pytest.mark.parametrize("name,sh,seeds,gain", [("tiny", TINY, (909, 1010, 1111), 4.0),
+                                                ("default", DEFAULT_B8, (1212, 1313, 1414), 6.0)])
+def test_greedy_ids_identical_in_f32_mode(name, sh, seeds, gain):
+    g = golden("composed.npz")
+    sd = helpers.make_state_dict(sh, seed=seeds[0], head_gain=gain)
+    img, sos, _, _ = helpers.make_embeddings(sh, seed=seeds[1])
+    emb = helpers.make_token_table(sh, seed=seeds[2])
+    model = make_model(sh, sd, F32)
+    model.eval()
+    ids, margins = model.generate(img.to(DEV), sos.to(DEV), emb.to(DEV), max_len=sh.L, return_margins=True)
+    ref_ids = torch.from_numpy(g[f"greedy_{name}_ids"])
+    ref_margins = torch.from_numpy(g[f"greedy_{name}_margins"])
+    assert float(ref_margins.min()) > 1e-3            # the fixture's decisions are far from ties
+    assert torch.equal(ids.cpu(), ref_ids)
+    live = ref_ids != sh.vocab - 1
+    assert (margins.cpu() - ref_margins)[live].abs().max().item() <= 1e-3
+    # bf16: identical wherever the reference's margin is well above bf16 noise, up to the first divergence
+    mb = make_model(sh, sd, BF16)
+    idb = mb.generate(img.to(DEV), sos.to(DEV), emb.to(DEV), max_len=sh.L).cpu()
+    safe = (ref_margins > 0.25).cumprod(dim=1).bool()
+    assert torch.equal(idb[safe], ref_ids[safe])
+
+
+def test_greedy_multi_block_matches_oracle():
+    sh = TINY
+    nb = 2
+    sds = [helpers.make_state_dict(sh, seed=940 + i, head_gain=4.0) for i in range(nb)]
+    full = dict(sds[0])
+    for k in ref_cpu.BLOCK_KEYS:
+        full[block_key(1, k, nb)] = sds[1][k]
+    img, sos, _, _ = helpers.make_embeddings(sh, seed=1515)
+    emb = helpers.make_token_table(sh, seed=1616)
+    pos = 0.3 * torch.randn(sh.S, sh.d, generator=torch.Generator().manual_seed(6))
+    model = make_model(sh, full, F32, n_blocks=nb, mask_mode="prefix_causal", activation="gelu")
+    V = sh.vocab
+    ids = model.generate(img.to(DEV), sos.to(DEV), emb.to(DEV), max_len=sh.L, pos=pos.to(DEV)).cpu()
+    blocks = [{k: sds[i][k] for k in ref_cpu.BLOCK_KEYS} for i in range(nb)]
+    head = {k: sds[0][k] for k in ref_cpu.PARAM_KEYS[12:]}
+    with torch.no_grad():
+        ref_ids, margins = ref_cpu.greedy_decode(img, sos, emb, blocks, head, sh.nhead, sh.L, V - 3, V - 2, V - 1,
+                                                 mask_mode="prefix_causal", activation="gelu", pos=pos, return_margins=True)
+    safe = (margins > 1e-3).cumprod(dim=1).bool()
+    assert safe.float().mean().item() > 0.5
+    assert torch.equal(ids[safe], ref_ids[safe])
+    with pytest.raises(ValueError, match="prefix_causal"):
+        make_model(sh, full, F32, n_blocks=nb).generate(img.to(DEV), sos.to(DEV), emb.to(DEV), max_len=4)
+
+
+# ---------------------------------------------------------------------------- drop-in surface
+def test_prefix_join_and_process_batch():
+    from image_caption_amd.img_text_concat import process_batch
+    B, P, L, d = 3, 5, 4, 64
+    img = torch.arange(B * P * d, dtype=torch.float32, device=DEV).reshape(B, P, d)
+    sos = 1e4 + torch.arange(B * d, dtype=torch.float32, device=DEV).reshape(B, 1, d)
+    cap = 2e4 + torch.arange(B * L * d, dtype=torch.float32, device=DEV).reshape(B, L, d)
+    ids = torch.zeros(B, L, dtype=torch.int64, device=DEV)
+    out = process_batch({"image_embeddings": img, "sos_embedding": sos, "caption_embeddings": cap,
+                         "caption_input_ids": ids, "caption_labels": ids + 1})
+    ref = ref_cpu.concat_prefix(img.cpu(), sos.cpu(), cap.cpu())
+    assert out["decoder_inputs"].shape == (P + 1 + L, B, d)
+    assert torch.equal(out["decoder_inputs"].cpu(), ref)
+    assert out["caption_labels"].dtype == torch.int64 and out["caption_labels"].shape == (B, L)
+
+
+def test_state_dict_and_init_match_reference_layout():
+    torch.manual_seed(42)
+    m = TransformerDecoder(64, 2, 6, 128, 0.1, 503)
+    assert list(m.state_dict().keys()) == list(ref_cpu.PARAM_KEYS)
+    # same constructors, same order => same initial weights as stock modules under the seed
+    torch.manual_seed(42)
+    attn = torch.nn.MultiheadAttention(64, 2, dropout=0.1)
+    lin1 = torch.nn.Linear(64, 128)
+    assert torch.equal(m.self_attn.in_proj_weight, attn.in_proj_weight) and torch.equal(m.linear1.weight, lin1.weight)
+    mask = m.create_caption_mask(21)
+    assert mask.shape == (21, 21) and float(mask.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        m(torch.zeros(21, 2, 64), None)
+
+
+def test_train_decoder_loop():
+    from image_caption_amd.config import DecoderConfig
+    from image_caption_amd.decoder import train_decoder
+    from image_caption_amd.synthetic import make_captions
+    cfg = DecoderConfig(d_model=768, nhead=8, dim_feedforward=2048, dropout=0.1, batch_size=8, num_epochs=2, device="cuda")
+    gen = torch.Generator().manual_seed(0)
+    N, S = 40, 229
+    ids, labels = make_captions(N, 32, 50260, gen)
+    data = {"decoder_inputs": torch.randn(S, N, 768, generator=gen), "caption_input_ids": ids, "caption_labels": labels}
+    logs = []
+    model = train_decoder(data, cfg, log=lambda *a: None, logger=logs.append)
+    hist = model.training_history
+    assert [list(h)[0] for h in hist] == ["train_loss", "test_loss", "train_loss", "test_loss"]
+    assert hist[2]["train_loss"] < hist[0]["train_loss"]
+    assert "total_runtime" in logs[-1]
