@@ -168,12 +168,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
     }
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
+// 64 columns per block; 16 row groups each sum a fixed interleaved subset of the
+// per-block partials, then a fixed-order fold: deterministic for a given grid
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta) {
+    __shared__ float sa[16][64], sb[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
-    dgamma[c] = a; dbeta[c] = b;
+    if (c < d)
+        for (int k = ty; k < nblk; k += 16) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
+    sa[ty][tx] = a; sb[ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < d) {
+        float ra = 0.f, rb = 0.f;
+        for (int j = 0; j < 16; ++j) { ra += sa[j][tx]; rb += sb[j][tx]; }
+        dgamma[c] = ra; dbeta[c] = rb;
+    }
 }
 
 int ln_bwd_blocks(long M) {
@@ -367,7 +377,7 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -98,3 +98,12 @@ class GradReducer:
         for w in self.works:
             w.wait()
         self.works = []
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous slice [lo, hi) of n samples owned by `rank` (remainder spread over
+    the first ranks).  Samples are independent along dim 1 of decoder_inputs /
+    dim 0 of the labels (decoder.py:163,166)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -14,6 +14,7 @@ What each stage replaces in the reference:
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -125,6 +126,32 @@ class ParamStore:
         return {key: self.param(key).clone() for key, _, _ in self.layout}
 
 
+class KernelTimer:
+    """Brackets chosen kernel launches with events recorded on the stream the kernels
+    are launched on (torch's current stream), so per-launch device time can be read
+    after the fact without synchronising inside the step."""
+
+    def __init__(self):
+        self.spans: Dict[str, list] = {}
+
+    @contextlib.contextmanager
+    def span(self, name: str):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        yield
+        e.record()
+        self.spans.setdefault(name, []).append((s, e))
+
+    def summary(self) -> Dict[str, tuple]:
+        """name -> (launch count, mean ms per launch)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = (len(ms), sum(ms) / max(1, len(ms)))
+        return out
+
+
 class _Weights:
     """Per-call view of the tensors the kernels read: matrices in compute dtype,
     biases / LayerNorm affine in f32."""
@@ -160,6 +187,10 @@ class DecoderEngine:
         _lib.load()
         self._bufs: Dict[str, torch.Tensor] = {}
         self.cdt = self.opt.compute_dtype
+        self.timer: Optional[KernelTimer] = None
+
+    def _span(self, name: str):
+        return self.timer.span(name) if self.timer is not None else contextlib.nullcontext()
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name: str, shape, dtype, device, zero: bool = False) -> torch.Tensor:
@@ -299,7 +330,8 @@ class DecoderEngine:
         amax = self.buf("ce_argmax", (Mh,), torch.int32, dev)
         loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         correct = torch.empty(1, dtype=torch.int32, device=dev)
-        ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws)
+        with self._span("logits_ce_fwd"):
+            ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws)
         if not want_grads:
             return loss_sum, correct, Mh
         # ---- head backward, one vocabulary slab at a time: logits are never materialised
@@ -314,9 +346,12 @@ class DecoderEngine:
             nv = min(slab, V - v0)
             ld = (nv + 127) // 128 * 128
             dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)
-            ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb)
-            ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first)
-            ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
+            with self._span("logits_ce_bwd_slab"):
+                ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb)
+            with self._span("head_dgrad_slab"):
+                ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first)
+            with self._span("head_wgrad_slab"):
+                ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
             first = False
             if on_grad_ready is not None:
                 on_grad_ready(HEAD_W, v0, nv)
