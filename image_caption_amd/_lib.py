@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("colsum", c_void_p),
         ("kv_cache", c_void_p), ("kv_q", c_int), ("kv_d", c_int), ("kv_B", c_int), ("kv_H", c_int), ("kv_hd", c_int),
         ("kv_smax", c_int), ("kv_s0", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", c_long),
     ]
 
 

@@ -26,7 +26,7 @@ constexpr int LDS_BYTES = 4 * CS_WAVE_BYTES;     // 69632 >= 2 stages * (16 KiB 
 constexpr int STAGE_BYTES = 32768;
 constexpr int TILE_BYTES = 16384;
 
-enum { EPI_STD = 0, EPI_CE_FWD = 1, EPI_CE_BWD = 2 };
+enum { EPI_STD = 0, EPI_CE_FWD = 1, EPI_CE_BWD = 2, EPI_STD_SIDE = 3 };
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -49,6 +49,8 @@ struct GemmArgs {
     const int64_t* labels; int ce_B, ce_L; int ce_col0;
     float* pmax; float* psum; float* psec; int* parg; float* zlabel; int np;
     const float* lse; float gscale; int store_cols;
+    int split_k; long split_stride;    // split-K: blockIdx.y owns a K range and writes slab C + y*split_stride
+    unsigned long long* stamps;      // diagnostic: 4 clock stamps per workgroup, NULL in normal use
 };
 
 // ------------------------------------------------------------------ tile order
@@ -103,127 +105,216 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int ks, in
 }
 
 // ------------------------------------------------------------------ operand fetch
+// A thread moves 4 chunks of 16 B per operand tile: chunk c = tid + 256*i.  The row (or
+// k-row) of chunk i is that of chunk 0 plus a constant, so one 32-bit offset per thread
+// serves all four loads; the per-i row advance goes into the (scalar) buffer descriptor,
+// and the four LDS destinations differ by a compile-time constant.
 struct OperandView {
     const bf16_t* base;   // first element of this block's panel
     long remaining;       // elements addressable from base
     long ld;
     int rows_left;        // valid rows (non-reduction index) from the panel start
 };
+struct ThreadPlan {
+    unsigned voff;        // byte offset of chunk 0 inside a k-tile (0xFFFFFFFF: never in range)
+    int lds0;             // LDS byte offset of chunk 0 inside a tile
+    int kc8;              // row-major: first k of this thread's chunk inside the k-tile
+};
 
 template <bool TR>
-__device__ __forceinline__ void fetch_tile(const OperandView& v, int k0, int K, int tid, u32x4 (&r)[4]) {
-    // base pointer advanced to this k-tile (wave-uniform), 32-bit offsets inside it
-    const long adv = TR ? (long)k0 * v.ld : (long)k0;
-    long rem = (v.remaining - adv) * 2;
-    rem = rem < 0 ? 0 : (rem > 0xFFFFFFF0L ? 0xFFFFFFF0L : rem);
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)(unsigned)rem, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + NTHREADS * i;
-        unsigned off;
-        if constexpr (!TR) {
-            const int row = c >> 3, kc = c & 7;
-            off = (unsigned)(((long)row * v.ld + kc * 8) * 2);
-            if (k0 + kc * 8 >= K) off = 0xFFFFFFFFu;
-        } else {
-            const int krow = c >> 4, rc = c & 15;
-            off = (unsigned)(((long)krow * v.ld + rc * 8) * 2);
-            if (rc * 8 >= v.rows_left || k0 + krow >= K) off = 0xFFFFFFFFu;
-        }
-        r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-        if constexpr (!TR) {
-            // a chunk that straddles K: zero the elements at k >= K (they belong to the row's padding)
-            const int kk = K - (k0 + (c & 7) * 8);
-            if (kk > 0 && kk < 8) {
-#pragma unroll
-                for (int dw = 0; dw < 4; ++dw) {
-                    if (2 * dw >= kk) r[i][dw] = 0u;
-                    else if (2 * dw + 1 >= kk) r[i][dw] &= 0xFFFFu;
-                }
-            }
-        }
+__device__ __forceinline__ ThreadPlan make_plan(const OperandView& v, int tid) {
+    ThreadPlan t;
+    if constexpr (!TR) {
+        const int row = tid >> 3, kc = tid & 7;
+        t.voff = (unsigned)(((long)row * v.ld + kc * 8) * 2);
+        t.lds0 = lds_off_rowmajor(row, kc);               // rows of chunk i: row + 32*i, same (row & 7)
+        t.kc8 = kc * 8;
+    } else {
+        const int krow = tid >> 4, rc = tid & 15;
+        t.voff = rc * 8 < v.rows_left ? (unsigned)(((long)krow * v.ld + rc * 8) * 2) : 0xFFFFFFFFu;
+        t.lds0 = lds_off_kmajor(krow, rc);                 // k-rows of chunk i: krow + 16*i, same swizzle bits
+        t.kc8 = 0;
     }
+    return t;
 }
 
 template <bool TR>
-__device__ __forceinline__ void stash_tile(char* tile, int tid, const u32x4 (&r)[4]) {
+__device__ __forceinline__ void fetch_tile(const OperandView& v, const ThreadPlan& t, int k0, int K, u32x4 (&r)[4]) {
+    const long step = (TR ? 16L : 32L) * v.ld;             // elements between chunk i and chunk i+1
+    const long adv = TR ? (long)k0 * v.ld : (long)k0;
+    unsigned off = t.voff;
+    if constexpr (!TR) {
+        if (k0 + t.kc8 >= K) off = 0xFFFFFFFFu;            // whole chunk beyond K
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = tid + NTHREADS * i;
-        int off;
-        if constexpr (!TR) off = lds_off_rowmajor(c >> 3, c & 7);
-        else off = lds_off_kmajor(c >> 4, c & 15);
-        *reinterpret_cast<u32x4*>(tile + off) = r[i];
+        // bytes addressable from this chunk row's base; reads past the operand's end return 0.
+        // Clamped to [0, 0xFFFFFFF0] with 32-bit scalar compares only (a 64-bit compare would
+        // go to the VALU and take VGPRs that in-flight loads own).
+        const long rem = (v.remaining - adv - i * step) * 2;
+        const int hi = (int)(rem >> 32);
+        const unsigned lo = (unsigned)rem;
+        const unsigned rec = hi < 0 ? 0u : (hi > 0 ? 0xFFFFFFF0u : (lo > 0xFFFFFFF0u ? 0xFFFFFFF0u : lo));
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv + i * step), 0, (int)rec, 0x00020000);
+        r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     }
+}
+
+// Registers -> LDS.  Only here (when the data is needed anyway, never right after the
+// load was issued) a row-major chunk that straddles a ragged K gets its elements at
+// k >= K zeroed; the test is wave-uniform and false for every tile but a ragged last one.
+template <bool TR>
+__device__ __forceinline__ void stash_tile(char* tile, const ThreadPlan& t, u32x4 (&r)[4], int k0, int K) {
+    if constexpr (!TR) {
+        if ((K & 7) != 0 && k0 + BK > K) {
+            const int kk = K - (k0 + t.kc8);
+            if (kk > 0 && kk < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int dw = 0; dw < 4; ++dw) {
+                        if (2 * dw >= kk) r[i][dw] = 0u;
+                        else if (2 * dw + 1 >= kk) r[i][dw] &= 0xFFFFu;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tile + t.lds0 + i * 4096) = r[i];
 }
 
 // ------------------------------------------------------------------ epilogues
 // All take the wave's 64x64 f32 tile in LDS (row stride CS_LD) and the global
-// coordinates (mw, nw) of its corner.
+// coordinates (mw, nw) of its corner.  A lane owns 4 fixed columns (n .. n+3) and
+// the rows it*4 + (lane>>4), it = 0..15.  Everything that depends only on the
+// column (bias) or only on the row (label, lse) is fetched once, ahead of the row
+// loop, and per-element side inputs (residual, gate, C for accumulate) are fetched
+// four rows ahead of their use, so no global-load latency sits inside the loop.
 
-__device__ __forceinline__ float epi_value(const GemmArgs& p, float v, long m, int n) {
-    if (p.bias) v += p.bias[n];
-    if (n < p.col_scale_n) v *= p.col_scale;
-    if (p.aux_out) store_from_f32(p.aux_out, m * p.ldaux + n, p.out_dtype, v);
-    if (p.act == CAPDEC_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (p.act == CAPDEC_ACT_GELU) v = gelu_f(v);
-    if (p.gate_mode == CAPDEC_GATE_RELU_OUT) {
-        const float g = load_as_f32(p.gate, m * p.ldg + n, p.gate_dtype);
-        v = (g != 0.f) ? v * p.gate_scale : 0.f;
-    } else if (p.gate_mode == CAPDEC_GATE_GELU_PRE) {
-        const float z = load_as_f32(p.gate, m * p.ldg + n, p.gate_dtype);
-        float f = gelu_grad_f(z);
-        if (p.gate_thr) f = dropout_keep(p.gate_k0, p.gate_k1, (uint32_t)(m * p.N + n), p.gate_thr) ? f * p.gate_scale : 0.f;
-        v *= f;
+__device__ __forceinline__ f32x4 load4_any(const void* base, long idx, int dtype, bool vec, int nvalid) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        if (dtype == CAPDEC_BF16) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)base + idx);
+            r = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        } else {
+            r = *reinterpret_cast<const f32x4*>((const float*)base + idx);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) r[e] = load_as_f32(base, idx + e, dtype);
     }
-    if (p.drop_thr) v = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)(m * p.N + n), p.drop_thr) ? v * p.drop_scale : 0.f;
-    if (p.residual) v += p.residual[m * p.ldr + n];
-    return v;
+    return r;
+}
+__device__ __forceinline__ void store4_any(void* base, long idx, int dtype, bool vec, int nvalid, const float (&v)[4]) {
+    if (vec) {
+        if (dtype == CAPDEC_BF16) {
+            bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+            *reinterpret_cast<bf16x4*>((bf16_t*)base + idx) = o;
+        } else {
+            *reinterpret_cast<f32x4*>((float*)base + idx) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) store_from_f32(base, idx + e, dtype, v[e]);
+    }
 }
 
+// SIDE = false: no per-element side input (residual / gate / accumulate): the row loop
+// contains no global load, so its stores are never waited for.
+// SIDE = true: side inputs of 4 rows are fetched together, then the 4 rows are finished.
+template <bool SIDE>
 __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
-    const int c4 = (lane & 15) * 4;
+    const int c4 = (lane & 15) * 4, g = lane >> 4;
     const int n = nw + c4;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec_ok = (n + 3 < p.N) && ((p.ldc & 3) == 0) && !p.kv_cache;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const long m = (long)mw + row;
-        if (m >= p.M || n >= p.N) continue;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
-        float v[4];
+    const int nvalid = min(4, p.N - n);                    // <= 0: this lane owns no column
+    const bool full = nvalid == 4;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = 0.f;
-            if (n + e < p.N) {
-                v[e] = epi_value(p, a[e], m, n + e);
-                if (p.accumulate) v[e] += ((const float*)p.C)[m * p.ldc + n + e];
-                csum[e] += v[e];
-            }
-        }
-        if (p.kv_cache && n >= p.kv_q) {
-            // K/V columns: cache[b][h][k|v][kv_s0 + s][j]
-            const int nn = n - p.kv_q;
-            const int which = nn / p.kv_d, rem = nn - which * p.kv_d;
-            const int hh = rem / p.kv_hd, j = rem - hh * p.kv_hd;
-            const long s = m / p.kv_B, b = m - s * p.kv_B;
-            const long dst = ((((b * p.kv_H + hh) * 2 + which) * p.kv_smax) + p.kv_s0 + s) * p.kv_hd + j;
+    for (int e = 0; e < 4; ++e) {
+        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
+        if (n + e < p.col_scale_n) scale4[e] = p.col_scale;
+    }
+    const bool vec_c = full && (p.ldc & 3) == 0;
+    const bool vec_r = full && (p.ldr & 3) == 0;
+    const bool vec_g = full && (p.ldg & 3) == 0;
+    const bool vec_x = full && (p.ldaux & 3) == 0;
+    const float relu_floor = p.act == CAPDEC_ACT_RELU ? 0.f : -INFINITY;
+
+    auto finish_row = [&](int it, f32x4 a, f32x4 res, f32x4 gat, f32x4 cin) {
+        const long m = (long)mw + it * 4 + g;
+        if (m >= p.M || nvalid <= 0) return;
+        f32x4 x = (a + bias4) * scale4;
+        const f32x4 pre = x;
+        if (p.act == CAPDEC_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) store_from_f32(p.kv_cache, dst + e, p.out_dtype, v[e]);
-        } else if (vec_ok) {
-            if (p.out_dtype == CAPDEC_BF16) {
-                bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-                *reinterpret_cast<bf16x4*>((bf16_t*)p.C + m * p.ldc + n) = o;
-            } else {
-                f32x4 o = {v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>((float*)p.C + m * p.ldc + n) = o;
-            }
+            for (int e = 0; e < 4; ++e) x[e] = gelu_f(x[e]);
         } else {
 #pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], relu_floor);
+        }
+        if constexpr (SIDE) {
+            if (p.gate_mode == CAPDEC_GATE_RELU_OUT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (gat[e] != 0.f) ? x[e] * p.gate_scale : 0.f;
+            } else if (p.gate_mode == CAPDEC_GATE_GELU_PRE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float f = gelu_grad_f(gat[e]);
+                    if (p.gate_thr) f = dropout_keep(p.gate_k0, p.gate_k1, (uint32_t)(m * p.N + n + e), p.gate_thr) ? f * p.gate_scale : 0.f;
+                    x[e] *= f;
+                }
+            }
+        }
+        if (p.drop_thr) {
+#pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) store_from_f32(p.C, m * p.ldc + n + e, p.out_dtype, v[e]);
+                x[e] = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)(m * p.N + n + e), p.drop_thr) ? x[e] * p.drop_scale : 0.f;
+        }
+        if constexpr (SIDE) x += res + cin;
+        float v[4], pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = e < nvalid ? x[e] : 0.f; pv[e] = pre[e]; csum[e] += v[e]; }
+        if (p.aux_out) store4_any(p.aux_out, m * p.ldaux + n, p.out_dtype, vec_x, nvalid, pv);
+        if (p.kv_cache && n >= p.kv_q) {
+            // K/V columns: cache[b][h][k|v][kv_s0 + s][j]; 4 consecutive columns stay inside one head (hd % 4 == 0)
+            const int nn = n - p.kv_q;
+            const int which = nn / p.kv_d, rem = nn - which * p.kv_d;
+            const int hh = rem / p.kv_hd, jj = rem - hh * p.kv_hd;
+            const long sq = m / p.kv_B, b = m - sq * p.kv_B;
+            const long dst = ((((b * p.kv_H + hh) * 2 + which) * p.kv_smax) + p.kv_s0 + sq) * p.kv_hd + jj;
+            store4_any(p.kv_cache, dst, p.out_dtype, full, nvalid, v);
+        } else {
+            store4_any(p.C, m * p.ldc + n, p.out_dtype, vec_c, nvalid, v);
+        }
+    };
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!SIDE) {
+#pragma unroll 2
+        for (int it = 0; it < 16; ++it)
+            finish_row(it, *reinterpret_cast<const f32x4*>(cs + (it * 4 + g) * CS_LD + c4), zero4, zero4, zero4);
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {
+            f32x4 res[4], gat[4], cin[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long m = (long)mw + (ch * 4 + j) * 4 + g;
+                const bool live = m < p.M && nvalid > 0;
+                res[j] = gat[j] = cin[j] = zero4;
+                if (p.residual && live) res[j] = load4_any(p.residual, m * p.ldr + n, CAPDEC_F32, vec_r, nvalid);
+                if (p.gate_mode != CAPDEC_GATE_NONE && live) gat[j] = load4_any(p.gate, m * p.ldg + n, p.gate_dtype, vec_g, nvalid);
+                if (p.accumulate && live) cin[j] = load4_any(p.C, m * p.ldc + n, CAPDEC_F32, vec_c, nvalid);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int it = ch * 4 + j;
+                finish_row(it, *reinterpret_cast<const f32x4*>(cs + (it * 4 + g) * CS_LD + c4), res[j], gat[j], cin[j]);
+            }
         }
     }
     if (p.colsum) {
@@ -232,7 +323,7 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
             float s = csum[e];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (lane < 16 && n + e < p.N) atomicAdd(p.colsum + n + e, s);
+            if (lane < 16 && e < nvalid) atomicAdd(p.colsum + n + e, s);
         }
     }
 }
@@ -247,28 +338,50 @@ __device__ __forceinline__ void top2_merge(Top2& t, float m1, int a1, float m2) 
     else t.m2 = fmaxf(t.m2, m1);
 }
 
+__device__ __forceinline__ int row_label(const GemmArgs& p, long m) {
+    const long l = m / p.ce_B, b = m - l * p.ce_B;
+    return (int)p.labels[b * p.ce_L + l];
+}
+
+// Row constants of the cross-entropy epilogues (label, lse) are fetched once per wave,
+// one row per lane, and parked in the 4 pad columns of the wave's LDS tile, so that the
+// row loops below contain no global load (and so never wait for their own stores).
+__device__ __forceinline__ void stage_row_consts(const GemmArgs& p, float* cs, int mw, int lane, int col0, bool want_lse) {
+    const long m = (long)mw + lane;
+    int lab = -1;
+    float lse = 0.f;
+    if (m < p.M) {
+        if (p.labels) lab = row_label(p, m) - col0;
+        if (want_lse) lse = p.lse[m];
+    }
+    cs[lane * CS_LD + 64] = __int_as_float(lab);
+    cs[lane * CS_LD + 65] = lse;
+}
+
 // per (row, 64-column slot): max, second max, argmax, sum exp(z - max); the label's logit
-__device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, const float* cs, int mw, int nw, int slot, int lane) {
-    const int c4 = (lane & 15) * 4;
+__device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, int mw, int nw, int slot, int lane) {
+    const int c4 = (lane & 15) * 4, g = lane >> 4;
     const int n = nw + c4;
+    const int nvalid = min(4, p.N - n);
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
+        if (e >= nvalid) bias4[e] = -INFINITY;              // columns past N never win and add exp(-inf) = 0
+    }
+    stage_row_consts(p, cs, mw, lane, 0, false);
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
+        const int row = it * 4 + g;
         const long m = (long)mw + row;
         const bool live = m < p.M;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
-        long label = -1;
-        if (live && p.labels) {
-            const long l = m / p.ce_B, b = m - l * p.ce_B;
-            label = p.labels[b * p.ce_L + l];
-        }
-        float z[4];
+        const f32x4 z = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4) + bias4;
+        const int lab = __float_as_int(cs[row * CS_LD + 64]);
         Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            z[e] = (n + e < p.N) ? a[e] + (p.bias ? p.bias[n + e] : 0.f) : -INFINITY;
-            if (n + e < p.N) top2_push(t, z[e], n + e);
-            if (live && (long)(n + e) == label) p.zlabel[m] = z[e];
+            if (e < nvalid) top2_push(t, z[e], n + e);
+            if (live && n + e == lab) p.zlabel[m] = z[e];
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
@@ -276,11 +389,8 @@ __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, const float* 
             const int oa1 = __shfl_xor(t.a1, o, 64);
             top2_merge(t, om1, oa1, om2);
         }
-        float s = 0.f;
-        if (t.m1 > -INFINITY) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s += (n + e < p.N) ? __expf(z[e] - t.m1) : 0.f;
-        }
+        const float mref = t.m1 > -INFINITY ? t.m1 : 0.f;
+        float s = __expf(z[0] - mref) + __expf(z[1] - mref) + __expf(z[2] - mref) + __expf(z[3] - mref);
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
         if (live && (lane & 15) == 0) {
@@ -291,36 +401,31 @@ __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, const float* 
 }
 
 // dl = (softmax - onehot) * gscale for one vocabulary slab
-__device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
-    const int c4 = (lane & 15) * 4;
+__device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, int mw, int nw, int lane) {
+    const int c4 = (lane & 15) * 4, g = lane >> 4;
     const int n = nw + c4;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nvalid = min(4, p.N - n);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
+    stage_row_consts(p, cs, mw, lane, p.ce_col0, true);
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
+        const int row = it * 4 + g;
         const long m = (long)mw + row;
         if (m >= p.M || n >= p.store_cols) continue;
         const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
-        const long l = m / p.ce_B, b = m - l * p.ce_B;
-        const long label = p.labels[b * p.ce_L + l];
-        const float lse = p.lse[m];
+        const int lab = __float_as_int(cs[row * CS_LD + 64]);
+        const float lse = cs[row * CS_LD + 65];
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = 0.f;
-            if (n + e < p.N) {
-                const float z = a[e] + (p.bias ? p.bias[n + e] : 0.f);
-                v[e] = (__expf(z - lse) - ((long)(n + e + p.ce_col0) == label ? 1.f : 0.f)) * p.gscale;
-                csum[e] += v[e];
-            }
+            v[e] = e < nvalid ? (__expf(a[e] + bias4[e] - lse) - (n + e == lab ? 1.f : 0.f)) * p.gscale : 0.f;
+            csum[e] += v[e];
         }
-        if (p.out_dtype == CAPDEC_BF16) {
-            bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-            *reinterpret_cast<bf16x4*>((bf16_t*)p.C + m * p.ldc + n) = o;
-        } else {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>((float*)p.C + m * p.ldc + n) = o;
-        }
+        store4_any(p.C, m * p.ldc + n, p.out_dtype, true, 4, v);
     }
     if (p.colsum) {
 #pragma unroll
@@ -328,17 +433,18 @@ __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, const float* 
             float s = csum[e];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (lane < 16 && n + e < p.N) atomicAdd(p.colsum + n + e, s);
+            if (lane < 16 && e < nvalid) atomicAdd(p.colsum + n + e, s);
         }
     }
 }
 
 template <int EPI>
-__device__ __forceinline__ void run_epilogue(const GemmArgs& p, const char* smem, int m0, int n0, int tile_n, int wave, int lane) {
+__device__ __forceinline__ void run_epilogue(const GemmArgs& p, char* smem, int m0, int n0, int tile_n, int wave, int lane) {
     const int wr = wave >> 1, wc = wave & 1;
-    const float* cs = reinterpret_cast<const float*>(smem + wave * CS_WAVE_BYTES);
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
     const int mw = m0 + wr * 64, nw = n0 + wc * 64;
-    if constexpr (EPI == EPI_STD) epilogue_std(p, cs, mw, nw, lane);
+    if constexpr (EPI == EPI_STD) epilogue_std<false>(p, cs, mw, nw, lane);
+    else if constexpr (EPI == EPI_STD_SIDE) epilogue_std<true>(p, cs, mw, nw, lane);
     else if constexpr (EPI == EPI_CE_FWD) epilogue_ce_fwd(p, cs, mw, nw, tile_n * 2 + wc, lane);
     else epilogue_ce_bwd(p, cs, mw, nw, lane);
 }
@@ -369,21 +475,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
+    // split-K: this block covers k-tiles [kt0, kt0 + nk) and writes its own f32 slab
+    const int nk_total = (p.K + BK - 1) / BK;
+    int kt0 = 0, nk = nk_total;
+    if (p.split_k > 1) {
+        const int kper = (nk_total + p.split_k - 1) / p.split_k;
+        kt0 = blockIdx.y * kper;
+        nk = min(kper, nk_total - kt0);
+        p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
+    }
+    const int kb = kt0 * BK;
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    // One k-tile of register prefetch: the loads of tile t+1 are issued before tile t is
+    // multiplied out of LDS and written to the other LDS stage after it.  (A second register
+    // set was tried: hipcc's wait-count insertion then drains every load at each LDS write,
+    // so it only cost registers.  Deeper prefetch lives in the LDS-DMA kernel below.)
     u32x4 ra[4], rb[4];
-    fetch_tile<A_TR>(va, 0, p.K, tid, ra);
-    fetch_tile<B_TR>(vb, 0, p.K, tid, rb);
-    stash_tile<A_TR>(smem, tid, ra);
-    stash_tile<B_TR>(smem + TILE_BYTES, tid, rb);
+    const ThreadPlan ta = make_plan<A_TR>(va, tid), tb = make_plan<B_TR>(vb, tid);
+    fetch_tile<A_TR>(va, ta, kb, p.K, ra);
+    fetch_tile<B_TR>(vb, tb, kb, p.K, rb);
+    stash_tile<A_TR>(smem, ta, ra, kb, p.K);
+    stash_tile<B_TR>(smem + TILE_BYTES, tb, rb, kb, p.K);
     __syncthreads();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
 
     for (int kt = 0; kt < nk; ++kt) {
         const char* sA = smem + (kt & 1) * STAGE_BYTES;
         const char* sB = sA + TILE_BYTES;
         const bool more = kt + 1 < nk;
+        const int knext = kb + (kt + 1) * BK;
         if (more) {
-            fetch_tile<A_TR>(va, (kt + 1) * BK, p.K, tid, ra);
-            fetch_tile<B_TR>(vb, (kt + 1) * BK, p.K, tid, rb);
+            fetch_tile<A_TR>(va, ta, knext, p.K, ra);
+            fetch_tile<B_TR>(vb, tb, knext, p.K, rb);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -400,12 +523,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
         }
         if (more) {
             char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            stash_tile<A_TR>(dA, tid, ra);
-            stash_tile<B_TR>(dA + TILE_BYTES, tid, rb);
+            stash_tile<A_TR>(dA, ta, ra, knext, p.K);
+            stash_tile<B_TR>(dA + TILE_BYTES, tb, rb, knext, p.K);
         }
         __syncthreads();
     }
 
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
     // stage accumulators: lane holds C[row = 4*(lane>>4) + r][col = lane & 15] of each 16x16 tile
     float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
 #pragma unroll
@@ -418,6 +542,134 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
     __builtin_amdgcn_wave_barrier();
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel, LDS-DMA ring
+// Same tile and epilogues, but operand tiles go global -> LDS directly
+// (buffer_load ... lds, 16 B per lane, no staging registers) into a ring of four
+// 32-deep stages.  Three stages are in flight while one is multiplied; the wait is a
+// COUNTED vmcnt (the two youngest stages stay in flight across the barrier), so a
+// tile's HBM/L2 latency is covered by three MFMA phases.  An LDS-DMA writes
+// wave-base + 16*lane, i.e. the LDS image is lane-linear per wave instruction;
+// the bank-conflict swizzle is therefore applied to the per-lane SOURCE address and
+// undone by the same XOR on the fragment read.  Needs K % 32 == 0 (other K: the
+// register-staged kernel above); M/N tails are out-of-range rows whose results are
+// never stored.
+constexpr int DBK = 32, DSTAGES = 4, DTILE_BYTES = 8192, DSTAGE_BYTES = 2 * DTILE_BYTES;
+
+// row-major [128 rows][32 k] bf16, 64-B rows; chunk (0..3) XOR 3*((row>>3)&1): conflict-free ds_read_b128
+__device__ __forceinline__ int dlds_rowmajor(int row, int kc) { return row * 64 + ((kc ^ (((row >> 3) & 1) * 3)) << 4); }
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 dread_frag(const char* tile, int rb, int lane) {
+    if constexpr (!TR) return *reinterpret_cast<const bf16x8*>(tile + dlds_rowmajor(rb + (lane & 15), lane >> 4));
+    else return read_frag<true>(tile, rb, 0, lane);
+}
+
+// byte offset (from the k-tile's base) this lane fetches for DMA instruction j of its wave
+template <bool TR>
+__device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int wave, int lane, int j) {
+    const int piece = 4 * j + wave;                        // 1-KiB piece of the tile image
+    if constexpr (!TR) {
+        const int row = 16 * piece + (lane >> 2), pc = lane & 3;
+        const int kc = pc ^ (((row >> 3) & 1) * 3);
+        return (unsigned)(((long)row * v.ld + kc * 8) * 2);
+    } else {
+        const int krow = 4 * piece + (lane >> 4), pc = lane & 15;
+        const int chunk = pc ^ (kswz(krow) << 1);
+        return chunk * 8 < v.rows_left ? (unsigned)(((long)krow * v.ld + chunk * 8) * 2) : 0xFFFFFFFFu;
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned (&off)[2], int k0, char* tile, int wave) {
+    const long adv = TR ? (long)k0 * v.ld : (long)k0;
+    const long rem = (v.remaining - adv) * 2;
+    const int hi = (int)(rem >> 32);
+    const unsigned lo = (unsigned)rem;
+    const unsigned rec = hi < 0 ? 0u : (hi > 0 ? 0xFFFFFFF0u : (lo > 0xFFFFFFF0u ? 0xFFFFFFF0u : lo));
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)rec, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, tile + (4 * j + wave) * 1024), 16, off[j], 0, 0, 0);
+}
+
+template <bool A_TR, bool B_TR, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    map_tile(tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    OperandView va, vb;
+    if (A_TR) { va.base = (const bf16_t*)p.A + m0; va.remaining = (long)p.K * p.lda - m0; }
+    else      { va.base = (const bf16_t*)p.A + (long)m0 * p.lda; va.remaining = (long)(p.M - m0) * p.lda; }
+    va.ld = p.lda; va.rows_left = p.M - m0;
+    if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
+    else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
+    vb.ld = p.ldb; vb.rows_left = p.N - n0;
+    const unsigned offa[2] = {dma_src_offset<A_TR>(va, wave, lane, 0), dma_src_offset<A_TR>(va, wave, lane, 1)};
+    const unsigned offb[2] = {dma_src_offset<B_TR>(vb, wave, lane, 0), dma_src_offset<B_TR>(vb, wave, lane, 1)};
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / DBK;
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    // a stage index past the last k-tile still issues its (harmless) loads, so that the
+    // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
+    auto dma_stage = [&](int kt) {
+        char* st = smem + (kt & (DSTAGES - 1)) * DSTAGE_BYTES;
+        dma_tile<A_TR>(va, offa, kt * DBK, st, wave);
+        dma_tile<B_TR>(vb, offb, kt * DBK, st + DTILE_BYTES, wave);
+    };
+    dma_stage(0);
+    dma_stage(1);
+    dma_stage(2);
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // 12 DMA instructions of this wave are outstanding (3 stages x 4); all but the youngest 8 = stage kt
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // every wave's share of stage kt has landed; stage kt-1 is no longer read
+        dma_stage(kt + 3);                   // refill the stage that was read in iteration kt-1
+        const char* sA = smem + (kt & (DSTAGES - 1)) * DSTAGE_BYTES;
+        const char* sB = sA + DTILE_BYTES;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = dread_frag<A_TR>(sA, wr * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = dread_frag<B_TR>(sB, wc * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // trailing refills must land before LDS is reused
+    __syncthreads();
+
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------ exact-f32 kernel (validation mode)
@@ -486,13 +738,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------ launch
+unsigned long long* g_stamps = nullptr;
+int g_gemm_mode = 0;     // diagnostic: 1 forces the register-staged kernel
+
 template <int EPI>
-int launch_gemm(const GemmArgs& a, int in_dtype, hipStream_t st) {
+int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
+    GemmArgs a = a_in;
+    a.stamps = g_stamps;
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
     const long nwg = (long)tm * tn;
     if (nwg <= 0) return CAPDEC_OK;
     CAPDEC_CHECK(nwg < (1L << 31), "gemm: too many tiles");
-    dim3 grid((unsigned)nwg), block(NTHREADS);
+    dim3 grid((unsigned)nwg, a.split_k > 1 ? a.split_k : 1), block(NTHREADS);
     if (in_dtype == CAPDEC_BF16) {
         CAPDEC_CHECK((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm(bf16): lda/ldb must be multiples of 8 (got %ld, %ld)", a.lda, a.ldb);
         CAPDEC_CHECK(aligned16(a.A) && aligned16(a.B), "gemm(bf16): A/B must be 16-byte aligned");
@@ -500,12 +757,18 @@ int launch_gemm(const GemmArgs& a, int in_dtype, hipStream_t st) {
     do {                                                                                               \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI>,                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);            \
+        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);       \
     } while (0)
+        // the DMA ring wins on row-major x row-major operands; reduction-major operands (transposing
+        // LDS reads, two per fragment) and split-K stay on the register-staged kernel
+        const bool use_dma = (a.K % DBK) == 0 && a.K >= DBK && !a.a_kmajor && !a.b_kmajor && a.split_k <= 1 && g_gemm_mode != 1;
         if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
         else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
         else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
@@ -585,7 +848,25 @@ __global__ void ce_reduce_kernel(const float* rowloss, const int32_t* rowcorrect
 
 uint32_t keyed_thr(const capdec_dropout& d) { return d.p > 0.f ? dropout_threshold(d.p) : 0u; }
 
+
+// out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long m = i / N, n = i - m * N;
+        float a = accumulate ? to_f32<T>(out[m * ldc + n]) : 0.f;
+        for (int s2 = 0; s2 < split; ++s2) a += ws[s2 * slab + i];
+        out[m * ldc + n] = from_f32<T>(a);
+    }
+}
+
 }  // namespace
+
+// diagnostic hook (not part of the declared ABI): clock stamps of every workgroup of the next GEMM launches
+extern "C" void capdecdbg_gemm_stamps(void* device_buffer) { g_stamps = (unsigned long long*)device_buffer; }
+extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
 
 // ==================================================================== C ABI
 extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
@@ -624,6 +905,32 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
         CAPDEC_CHECK((a.kv_q == 0 || a.kv_q == a.kv_d) && a.N == a.kv_q + 2 * a.kv_d && (a.M % a.kv_B) == 0 && a.kv_s0 >= 0 && a.kv_s0 + a.M / a.kv_B <= a.kv_smax,
                      "gemm: kv scatter out of range (N=%d, M=%d, s0=%d, smax=%d)", a.N, a.M, a.kv_s0, a.kv_smax);
     }
+    // split-K for plain products whose tile grid cannot fill the chip (weight gradients: few tiles, very deep K)
+    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int nkt = (a.K + BK - 1) / BK;
+    const bool plain = !a.bias && a.col_scale_n == 0 && a.act == CAPDEC_ACT_NONE && !a.drop_thr && !a.residual &&
+                       a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache;
+    if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 192 && nkt >= 32) {
+        long split = 512 / tiles;
+        if (split > 8) split = 8;
+        if (split > nkt / 8) split = nkt / 8;
+        const long slab = (long)a.M * a.N;
+        if (split > 1 && d->workspace_bytes >= split * slab * 4) {
+            GemmArgs b = a;
+            b.C = d->workspace; b.ldc = a.N; b.out_dtype = CAPDEC_F32; b.accumulate = 0;
+            b.split_k = (int)split; b.split_stride = slab;
+            int rc = launch_gemm<EPI_STD>(b, d->in_dtype, (hipStream_t)stream);
+            if (rc) return rc;
+            const int nb = (int)((slab + 255) / 256 > 2048 ? 2048 : (slab + 255) / 256);
+            if (a.out_dtype == CAPDEC_BF16)
+                hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (bf16_t*)a.C, a.ldc, a.accumulate);
+            else
+                hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (float*)a.C, a.ldc, a.accumulate);
+            CAPDEC_LAUNCH_CHECK();
+            return CAPDEC_OK;
+        }
+    }
+    if (a.residual || a.accumulate || a.gate_mode != CAPDEC_GATE_NONE) return launch_gemm<EPI_STD_SIDE>(a, d->in_dtype, (hipStream_t)stream);
     return launch_gemm<EPI_STD>(a, d->in_dtype, (hipStream_t)stream);
 }
 

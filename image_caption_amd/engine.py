@@ -387,12 +387,13 @@ class DecoderEngine:
         Mt = M - r0
         k_attn, k_r1, k_h, k_r2 = sv["keys"]
         G = lambda name: grads[block_key(i, name, nbk)]           # noqa: E731
+        skws = self.buf("splitk_ws", (8 * max(3 * d * d, d * ff) * 4,), torch.uint8, dev)
         for name in ("self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias", "linear2.bias"):
             G(name).zero_()
         # ---- MLP
         g2 = self.buf("g_res", (Mt, d), cdt, dev)
         ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"))
-        ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True)
+        ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         if self.opt.activation == "relu":
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
@@ -400,7 +401,7 @@ class DecoderEngine:
         else:
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
                      gate_drop=k_h, colsum=G("linear1.bias"))
-        ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
+        ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
         dh2 = self.buf("dh", (Mt, d), cdt, dev)
         ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
         dx_mid = self.buf(f"dx_mid", (Mt, d), torch.float32, dev)
@@ -409,7 +410,7 @@ class DecoderEngine:
         # ---- attention
         g1 = g2
         ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"))
-        ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
+        ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
         dattn = self.buf("dattn", (M, d), cdt, dev)
         ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
         dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
@@ -420,12 +421,12 @@ class DecoderEngine:
         h1 = sv["h1"]
         if q_start == 0:
             ops.colsum(dqkv, gin_b)
-            ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True)
+            ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
         else:
             ops.colsum(dqkv[r0:, :d], gin_b[:d])
             ops.colsum(dqkv[:, d:], gin_b[d:])
-            ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True)
-            ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True)
+            ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
+            ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
         dh1 = self.buf("dh1", (M, d), torch.float32, dev)

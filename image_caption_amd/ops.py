@@ -77,7 +77,7 @@ def _ld(t: torch.Tensor) -> int:
 
 def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
          act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
-         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None):
+         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
     B is [N,K] (or [K,N] if b_kmajor)."""
     require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache)
@@ -112,6 +112,9 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
         qcols, dm, Bk, H, hd, smax, s0 = kv_geom
         assert kv_cache.dtype == Cout.dtype
         d.kv_cache, d.kv_q, d.kv_d, d.kv_B, d.kv_H, d.kv_hd, d.kv_smax, d.kv_s0 = ptr(kv_cache), qcols, dm, Bk, H, hd, smax, s0
+    if workspace is not None:
+        require_cuda(workspace)
+        d.workspace, d.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
     return Cout
 

@@ -110,6 +110,9 @@ typedef struct {
     /* K/V-cache scatter (greedy decoding): columns >= kv_q (kv_q = 0 or kv_d; N = kv_q + 2*kv_d)
      * go to kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_q go to C. */
     void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
+    /* optional scratch: with >= 8*M*N*4 bytes a plain bf16 product (no epilogue term) whose tile grid
+     * is too small to fill the GPU is split along K into f32 slabs and summed in a fixed order */
+    void* workspace; long workspace_bytes;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);

@@ -49,6 +49,25 @@ def test_gemm_layouts(dtype, tol, akm, bkm, M, N, K):
     close(out, ref, tol, "gemm")
 
 
+@pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
+def test_gemm_split_k(M, N, K, out):
+    # weight-gradient shape: few output tiles, deep K; both operands reduction-major
+    A = rnd(K, M, dtype=torch.bfloat16, seed=70)
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.1, seed=71)
+    ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device=DEV)
+    ref = A.float().t() @ B.float()
+    got = torch.full((M, N), float("nan"), device=DEV, dtype=out)
+    ops.gemm(A, B, got, a_kmajor=True, b_kmajor=True, workspace=ws)
+    close(got, ref, 1e-2 if out == torch.bfloat16 else 2e-3, "split-k")
+    plain = torch.empty(M, N, device=DEV, dtype=out)
+    ops.gemm(A, B, plain, a_kmajor=True, b_kmajor=True)
+    close(got, plain, 1e-2 if out == torch.bfloat16 else 1e-5, "split-k vs single pass")
+    if out == torch.float32:
+        acc = ref.clone()
+        ops.gemm(A, B, acc, a_kmajor=True, b_kmajor=True, workspace=ws, accumulate=True)
+        close(acc, 2 * ref, 2e-3, "split-k accumulate")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float32, 3e-5)])
 def test_gemm_epilogue_forward(dtype, tol):
     M, N, K = 300, 264, 192
