@@ -101,7 +101,8 @@ SIGNATURES = {
                                      c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                           c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int,
-                                          c_void_p, c_long, c_void_p, c_void_p]),
+                                          c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
+    "capdec_logits_ce_bwd_workspace": (c_long, [c_long, c_int]),
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),

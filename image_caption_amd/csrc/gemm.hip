@@ -49,6 +49,7 @@ struct GemmArgs {
     const int64_t* labels; int ce_B, ce_L; int ce_col0;
     float* pmax; float* psum; float* psec; int* parg; float* zlabel; int np;
     const float* lse; float gscale; int store_cols;
+    float* colpart; long ld_colpart;  // CE backward: per-(64-row group) column sums, [ceil(M/64)][ld_colpart]
     int split_k; long split_stride;    // split-K: blockIdx.y owns a K range and writes slab C + y*split_stride
     unsigned long long* stamps;      // diagnostic: 4 clock stamps per workgroup, NULL in normal use
 };
@@ -358,58 +359,54 @@ __device__ __forceinline__ void stage_row_consts(const GemmArgs& p, float* cs, i
     cs[lane * CS_LD + 65] = lse;
 }
 
-// per (row, 64-column slot): max, second max, argmax, sum exp(z - max); the label's logit
+// per (row, 64-column slot): max, second max, argmax, sum exp(z - max); the label's logit.
+// One ROW per lane: the wave's 64x64 tile (bias already added, columns past N = -inf) is read
+// back row-wise (row stride 68 floats puts 16 consecutive rows on 16 different 16-B bank slots,
+// so the ds_read_b128 are conflict-free), and the whole reduction over the 64 columns stays
+// inside the lane -- no cross-lane traffic, no global loads, no bounds checks.
 __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, int mw, int nw, int slot, int lane) {
-    const int c4 = (lane & 15) * 4, g = lane >> 4;
-    const int n = nw + c4;
-    const int nvalid = min(4, p.N - n);
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    const long m = (long)mw + lane;
+    const bool live = m < p.M;
+    int lab = -1;
+    if (live && p.labels) lab = row_label(p, m) - nw;       // column of the label inside this slot, if 0..63
+    const float* row = cs + lane * CS_LD;
+    float m1 = -INFINITY, m2 = -INFINITY, zl = 0.f;
+    int a1 = 0x7fffffff;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
-        if (e >= nvalid) bias4[e] = -INFINITY;              // columns past N never win and add exp(-inf) = 0
-    }
-    stage_row_consts(p, cs, mw, lane, 0, false);
-#pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + g;
-        const long m = (long)mw + row;
-        const bool live = m < p.M;
-        const f32x4 z = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4) + bias4;
-        const int lab = __float_as_int(cs[row * CS_LD + 64]);
-        Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (e < nvalid) top2_push(t, z[e], n + e);
-            if (live && n + e == lab) p.zlabel[m] = z[e];
+            const int c = c4 * 4 + e;
+            const float z = v[e];
+            const bool gt = z > m1;                          // strict: the lowest index wins a tie
+            m2 = gt ? m1 : fmaxf(m2, z);
+            a1 = gt ? nw + c : a1;
+            m1 = gt ? z : m1;
+            zl = c == lab ? z : zl;
         }
+    }
+    float sum = 0.f;
+    const float mref = m1 > -INFINITY ? m1 : 0.f;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const float om1 = __shfl_xor(t.m1, o, 64), om2 = __shfl_xor(t.m2, o, 64);
-            const int oa1 = __shfl_xor(t.a1, o, 64);
-            top2_merge(t, om1, oa1, om2);
-        }
-        const float mref = t.m1 > -INFINITY ? t.m1 : 0.f;
-        float s = __expf(z[0] - mref) + __expf(z[1] - mref) + __expf(z[2] - mref) + __expf(z[3] - mref);
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-        if (live && (lane & 15) == 0) {
-            const long o = m * p.np + slot;
-            p.pmax[o] = t.m1; p.psec[o] = t.m2; p.parg[o] = t.a1; p.psum[o] = s;
-        }
+        for (int e = 0; e < 4; ++e) sum += __expf(v[e] - mref);
+    }
+    if (live) {
+        const long o = m * p.np + slot;
+        p.pmax[o] = m1; p.psec[o] = m2; p.parg[o] = a1; p.psum[o] = sum;
+        if (lab >= 0 && lab < 64) p.zlabel[m] = zl;
     }
 }
 
-// dl = (softmax - onehot) * gscale for one vocabulary slab
+// dl = (softmax - onehot) * gscale for one vocabulary slab (tile holds z = logits incl. bias; -inf past N)
 __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, int mw, int nw, int lane) {
     const int c4 = (lane & 15) * 4, g = lane >> 4;
     const int n = nw + c4;
     const int nvalid = min(4, p.N - n);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
     stage_row_consts(p, cs, mw, lane, p.ce_col0, true);
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
@@ -422,20 +419,51 @@ __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, in
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = e < nvalid ? (__expf(a[e] + bias4[e] - lse) - (n + e == lab ? 1.f : 0.f)) * p.gscale : 0.f;
+            v[e] = (__expf(a[e] - lse) - (n + e == lab ? 1.f : 0.f)) * p.gscale;      // exp(-inf) = 0 past N
             csum[e] += v[e];
         }
         store4_any(p.C, m * p.ldc + n, p.out_dtype, true, 4, v);
     }
-    if (p.colsum) {
+    if (p.colpart) {
+        // column sums of this wave's 64 rows -> one row of the partial buffer (plain 16-B stores;
+        // atomics on the bias gradient would collide 128-fold per column)
+        f32x4 t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float s = csum[e];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (lane < 16 && e < nvalid) atomicAdd(p.colsum + n + e, s);
+            t[e] = s;
+        }
+        // a wave whose 64 rows all lie past M owns no row of the [ceil(M/64)][ld] partial buffer
+        if (lane < 16 && n < p.store_cols && mw < p.M) *reinterpret_cast<f32x4*>(p.colpart + (long)(mw >> 6) * p.ld_colpart + n) = t;
+    }
+}
+
+// Accumulators -> the wave's LDS tile.  A lane holds C[row = 4*(lane>>4) + r][col = lane & 15] of
+// each 16x16 tile, i.e. only 4 distinct columns: for the cross-entropy epilogues the column bias is
+// added here (and columns past N become -inf, so they never win a max and add exp(-inf) = 0), which
+// leaves their row loops free of bias loads and bounds checks.
+template <int EPI>
+__device__ __forceinline__ void stage_acc(const GemmArgs& p, char* smem, const f32x4 (&acc)[4][4], int n0, int wave, int lane) {
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
+    float cb[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+            cb[j] = n < p.N ? (p.bias ? p.bias[n] : 0.f) : -INFINITY;
         }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r] + cb[j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int EPI>
@@ -530,17 +558,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-    // stage accumulators: lane holds C[row = 4*(lane>>4) + r][col = lane & 15] of each 16x16 tile
-    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
-    __builtin_amdgcn_wave_barrier();
+    stage_acc<EPI>(p, smem, acc, n0, wave, lane);
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
@@ -567,10 +585,9 @@ __device__ __forceinline__ bf16x8 dread_frag(const char* tile, int rb, int lane)
     else return read_frag<true>(tile, rb, 0, lane);
 }
 
-// byte offset (from the k-tile's base) this lane fetches for DMA instruction j of its wave
+// byte offset (from the k-tile's base) a lane fetches for 1-KiB piece `piece` of a tile image
 template <bool TR>
-__device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int wave, int lane, int j) {
-    const int piece = 4 * j + wave;                        // 1-KiB piece of the tile image
+__device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int piece, int lane) {
     if constexpr (!TR) {
         const int row = 16 * piece + (lane >> 2), pc = lane & 3;
         const int kc = pc ^ (((row >> 3) & 1) * 3);
@@ -582,7 +599,8 @@ __device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int wav
     }
 }
 
-template <bool TR>
+// NJ pieces per wave; piece j of wave w is image piece NW*j + w
+template <bool TR, int NJ, int NW>
 __device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned (&off)[2], int k0, char* tile, int wave) {
     const long adv = TR ? (long)k0 * v.ld : (long)k0;
     const long rem = (v.remaining - adv) * 2;
@@ -591,17 +609,34 @@ __device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned (&
     const unsigned rec = hi < 0 ? 0u : (hi > 0 ? 0xFFFFFFF0u : (lo > 0xFFFFFFF0u ? 0xFFFFFFF0u : lo));
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)rec, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, tile + (4 * j + wave) * 1024), 16, off[j], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, tile + (NW * j + wave) * 1024), 16, off[j], 0, 0, 0);
 }
 
-template <bool A_TR, bool B_TR, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) {
+// WM = 2: 128x128 tile, 4 waves, two workgroups per CU.  WM = 4: 256x128 tile, 8 waves, one
+// workgroup per CU: the B panel is shared by twice as many MFMAs, which cuts the L2 -> LDS
+// traffic per FLOP by a quarter (the 128x128 ring is L2-bandwidth bound on the K=768 products).
+// Row-major A only reaches WM = 4 (a reduction-major A image has 128-column rows).
+template <int WM> struct DmaGeo {
+    static constexpr int NW = 2 * WM;                       // waves
+    static constexpr int BMV = 64 * WM;                     // tile rows
+    static constexpr int A_BYTES = BMV * 64;                // one 32-deep A image
+    static constexpr int STAGE = A_BYTES + DTILE_BYTES;
+    static constexpr int NJB = 8 / NW;                      // B pieces per wave
+    static constexpr int RING = DSTAGES * STAGE;
+    static constexpr int CSTAGE = NW * CS_WAVE_BYTES;
+    static constexpr int LDS = RING > CSTAGE ? RING : CSTAGE;
+};
+
+template <bool A_TR, bool B_TR, int EPI, int WM>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_bf16_dma_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    using G = DmaGeo<WM>;
+    static_assert(WM == 2 || !A_TR, "256-row tiles need a row-major A");
+    const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + BN - 1) / BN;
     int tile_m, tile_n;
     map_tile(tm, tn, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * G::BMV, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -613,8 +648,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) 
     if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
     else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
     vb.ld = p.ldb; vb.rows_left = p.N - n0;
-    const unsigned offa[2] = {dma_src_offset<A_TR>(va, wave, lane, 0), dma_src_offset<A_TR>(va, wave, lane, 1)};
-    const unsigned offb[2] = {dma_src_offset<B_TR>(vb, wave, lane, 0), dma_src_offset<B_TR>(vb, wave, lane, 1)};
+    const unsigned offa[2] = {dma_src_offset<A_TR>(va, wave, lane), dma_src_offset<A_TR>(va, G::NW + wave, lane)};
+    const unsigned offb[2] = {dma_src_offset<B_TR>(vb, wave, lane), G::NJB > 1 ? dma_src_offset<B_TR>(vb, G::NW + wave, lane) : 0u};
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -627,9 +662,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) 
     // a stage index past the last k-tile still issues its (harmless) loads, so that the
     // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
     auto dma_stage = [&](int kt) {
-        char* st = smem + (kt & (DSTAGES - 1)) * DSTAGE_BYTES;
-        dma_tile<A_TR>(va, offa, kt * DBK, st, wave);
-        dma_tile<B_TR>(vb, offb, kt * DBK, st + DTILE_BYTES, wave);
+        char* st = smem + (kt & (DSTAGES - 1)) * G::STAGE;
+        dma_tile<A_TR, 2, G::NW>(va, offa, kt * DBK, st, wave);
+        dma_tile<B_TR, G::NJB, G::NW>(vb, offb, kt * DBK, st + G::A_BYTES, wave);
     };
     dma_stage(0);
     dma_stage(1);
@@ -637,12 +672,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) 
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
 
     for (int kt = 0; kt < nk; ++kt) {
-        // 12 DMA instructions of this wave are outstanding (3 stages x 4); all but the youngest 8 = stage kt
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // three stages (2 + NJB DMA instructions each) of this wave are outstanding; all but the
+        // two youngest stages = stage kt
+        if constexpr (G::NJB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // every wave's share of stage kt has landed; stage kt-1 is no longer read
         dma_stage(kt + 3);                   // refill the stage that was read in iteration kt-1
-        const char* sA = smem + (kt & (DSTAGES - 1)) * DSTAGE_BYTES;
-        const char* sB = sA + DTILE_BYTES;
+        const char* sA = smem + (kt & (DSTAGES - 1)) * G::STAGE;
+        const char* sB = sA + G::A_BYTES;
         bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = dread_frag<A_TR>(sA, wr * 64 + i * 16, lane);
@@ -658,16 +695,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_dma_kernel(GemmArgs p) 
     __syncthreads();
 
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    stage_acc<EPI>(p, smem, acc, n0, wave, lane);
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
@@ -731,7 +759,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         for (int j = 0; j < 8; ++j) {
             const int mm = ty * 8 + i, nn = tx * 8 + j;
             const int w = (mm >> 6) * 2 + (nn >> 6);
-            reinterpret_cast<float*>(smem + w * CS_WAVE_BYTES)[(mm & 63) * CS_LD + (nn & 63)] = acc[i][j];
+            float cbias = 0.f;
+            if constexpr (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) cbias = n0 + nn < p.N ? (p.bias ? p.bias[n0 + nn] : 0.f) : -INFINITY;
+            reinterpret_cast<float*>(smem + w * CS_WAVE_BYTES)[(mm & 63) * CS_LD + (nn & 63)] = acc[i][j] + cbias;
         }
     __syncthreads();
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
@@ -759,17 +789,29 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         if (!attr_set) {                                                                               \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI, 2>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, DmaGeo<2>::LDS);     \
             attr_set = true;                                                                           \
         }                                                                                              \
-        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a); \
+        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI, 2>), grid, block, DmaGeo<2>::LDS, st, a); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);       \
     } while (0)
         // the DMA ring wins on row-major x row-major operands; reduction-major operands (transposing
         // LDS reads, two per fragment) and split-K stay on the register-staged kernel
         const bool use_dma = (a.K % DBK) == 0 && a.K >= DBK && !a.a_kmajor && !a.b_kmajor && a.split_k <= 1 && g_gemm_mode != 1;
-        if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
+        const long big_tiles = (long)((a.M + 255) / 256) * tn;
+        // 256-row tiles pay off only when the main loop dominates (deep K); with K = 768 the exposed epilogue of
+        // the single resident workgroup costs more than the saved L2 traffic (A/B in tools/gemm_bench.py)
+        const bool use_big = use_dma && ((big_tiles >= 512 && a.K >= 2048 && g_gemm_mode != 2) || g_gemm_mode == 3);
+        if (use_big) {
+            static bool big_attr = false;
+            if (!big_attr) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DmaGeo<4>::LDS);
+                big_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 4>), dim3((unsigned)big_tiles), dim3(512), DmaGeo<4>::LDS, st, a);
+        } else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
         else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
         else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
         else CAPDEC_GEMM_CASE(true, true);
@@ -850,6 +892,15 @@ uint32_t keyed_thr(const capdec_dropout& d) { return d.p > 0.f ? dropout_thresho
 
 
 // out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
+// bias gradient of one vocabulary slab: dbias[n] = sum over 64-row groups of the partial column sums
+__global__ void colpart_reduce_kernel(const float* part, int nrows, long ld, int nv, float* out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nv) return;
+    float a = 0.f;
+    for (int r = 0; r < nrows; ++r) a += part[(long)r * ld + n];
+    out[n] = a;
+}
+
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -1013,21 +1064,36 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     return CAPDEC_OK;
 }
 
+extern "C" long capdec_logits_ce_bwd_workspace(long M, int nv) {
+    return ((M + 63) / 64) * (long)((nv + BN - 1) / BN * BN) * 4;
+}
+
 extern "C" int capdec_logits_ce_bwd_slab(const void* h, const void* W, const float* bias, int dtype,
                                          long M, int V, int d, long ldh, long ldw,
                                          const int64_t* labels, int B, int L, const float* lse, float gscale,
-                                         int v0, int nv, void* dl, long ld_dl, float* dbias, void* stream) {
+                                         int v0, int nv, void* dl, long ld_dl, float* dbias,
+                                         void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && labels && lse && dl, "logits_ce_bwd_slab: null pointer");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_slab: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(v0 >= 0 && nv > 0 && v0 + nv <= V, "logits_ce_bwd_slab: slab [%d,%d) outside vocabulary %d", v0, v0 + nv, V);
     CAPDEC_CHECK(ld_dl >= nv && (ld_dl % 4) == 0 && ld_dl <= (long)((nv + BN - 1) / BN) * BN,
                  "logits_ce_bwd_slab: ld_dl (%ld) must be a multiple of 4 in [nv, roundup128(nv)]", ld_dl);
+    if (dbias && (!workspace || workspace_bytes < capdec_logits_ce_bwd_workspace(M, nv))) {
+        capdec_set_error("logits_ce_bwd_slab: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_bwd_workspace(M, nv));
+        return CAPDEC_ERR_WORKSPACE;
+    }
     GemmArgs a;
     const size_t esz = dtype == CAPDEC_BF16 ? 2 : 4;
     fill_head_args(a, h, (const char*)W + (size_t)v0 * ldw * esz, bias ? bias + v0 : nullptr, M, nv, d, ldh, ldw);
     a.C = dl; a.ldc = ld_dl; a.out_dtype = dtype; a.store_cols = (int)ld_dl;
     a.labels = labels; a.ce_B = B; a.ce_L = L; a.ce_col0 = v0;
     a.lse = lse; a.gscale = gscale;
-    a.colsum = dbias ? dbias + v0 : nullptr;
-    return launch_gemm<EPI_CE_BWD>(a, dtype, (hipStream_t)stream);
+    const long ldp = (long)((nv + BN - 1) / BN) * BN;
+    if (dbias) { a.colpart = (float*)workspace; a.ld_colpart = ldp; }
+    int rc = launch_gemm<EPI_CE_BWD>(a, dtype, (hipStream_t)stream);
+    if (rc || !dbias) return rc;
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (int)((M + 63) / 64), ldp, nv, dbias + v0);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
 }

@@ -340,14 +340,14 @@ class DecoderEngine:
         dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev)
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
-        gb.zero_()
+        bws = self.buf("ce_bwd_ws", (ops.logits_ce_bwd_workspace(Mh, slab),), torch.uint8, dev)
         first = True
         for v0 in range(0, V, slab):
             nv = min(slab, V - v0)
             ld = (nv + 127) // 128 * 128
             dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)
             with self._span("logits_ce_bwd_slab"):
-                ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb)
+                ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
             with self._span("head_dgrad_slab"):
                 ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first)
             with self._span("head_wgrad_slab"):

@@ -184,12 +184,17 @@ def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, work
                                            workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
 
 
-def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias):
-    require_cuda(h, W, bias, labels, lse, dl, dbias)
+def logits_ce_bwd_workspace(M, nv) -> int:
+    return _lib.load().capdec_logits_ce_bwd_workspace(M, nv)
+
+
+def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias, workspace=None):
+    require_cuda(h, W, bias, labels, lse, dl, dbias, workspace)
     M, d = h.shape
     V = W.shape[0]
+    wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0
     check(_lib.load().capdec_logits_ce_bwd_slab(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
-                                                ptr(lse), gscale, v0, nv, ptr(dl), _ld(dl), ptr(dbias), _st()),
+                                                ptr(lse), gscale, v0, nv, ptr(dl), _ld(dl), ptr(dbias), ptr(workspace), wsb, _st()),
           "capdec_logits_ce_bwd_slab")
 
 

@@ -177,13 +177,16 @@ int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dt
 
 /* Backward of the mean loss w.r.t. logits, one vocabulary slab [v0, v0+nv):
  * dl[m, n-v0] = (exp(z[m,n] - lse[m]) - [n == label[m]]) * gscale, written to
- * dl [M, ld_dl] of `dtype` (columns nv..ld_dl-1 zero-filled); dbias[v0+..] +=
- * column sums (atomic, f32).  The caller then forms dH += dl W_slab and
- * dW_slab = dl^T H with capdec_gemm_bias_act. */
+ * dl [M, ld_dl] of `dtype` (columns nv..ld_dl-1 zero-filled); dbias[v0 .. v0+nv) is
+ * OVERWRITTEN with the column sums (fixed-order reduction through `workspace` of
+ * capdec_logits_ce_bwd_workspace(M, nv) bytes; both may be NULL).  The caller then forms
+ * dH += dl W_slab and dW_slab = dl^T H with capdec_gemm_bias_act. */
+long capdec_logits_ce_bwd_workspace(long M, int nv);
 int capdec_logits_ce_bwd_slab(const void* h, const void* W, const float* bias, int dtype,
                               long M, int V, int d, long ldh, long ldw,
                               const int64_t* labels, int B, int L, const float* lse, float gscale,
-                              int v0, int nv, void* dl, long ld_dl, float* dbias, void* stream);
+                              int v0, int nv, void* dl, long ld_dl, float* dbias,
+                              void* workspace, long workspace_bytes, void* stream);
 
 /* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
  * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */

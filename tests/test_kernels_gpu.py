@@ -298,7 +298,7 @@ def test_logits_ce(dtype, tol, B, L, V, d):
     close(margin, top2.values[:, 0] - top2.values[:, 1], 0.1 if dtype == torch.bfloat16 else 1e-3, "margin")
     # backward, slab by slab
     loss_ref.backward()
-    dbias = torch.zeros(V, device=DEV)
+    dbias = torch.full((V,), float("nan"), device=DEV)
     dH = torch.zeros(M, d, device=DEV)
     dW = torch.empty(V, d, device=DEV)
     slab = 256 if V < 1000 else 8192
@@ -306,7 +306,8 @@ def test_logits_ce(dtype, tol, B, L, V, d):
         nv = min(slab, V - v0)
         ld = (nv + 127) // 128 * 128
         dl = torch.full((M, ld), float("nan"), device=DEV, dtype=dtype)
-        ops.logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, 1.0 / M, v0, nv, dl, dbias)
+        bws = torch.empty(ops.logits_ce_bwd_workspace(M, nv), dtype=torch.uint8, device=DEV)
+        ops.logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, 1.0 / M, v0, nv, dl, dbias, bws)
         dl_ref = (torch.softmax(z.detach(), -1) - torch.nn.functional.one_hot(tgt, V))[:, v0:v0 + nv] / M
         close(dl[:, :nv], dl_ref, 2e-2 if dtype == torch.bfloat16 else 1e-5, "dl")
         assert dl[:, nv:].abs().max().item() == 0 if ld > nv else True

@@ -61,8 +61,9 @@ def main():
     slab = 8192
     dl = torch.empty(Mt, slab, device=DEV, dtype=BF)
     dbias = torch.zeros(V, device=DEV)
+    bws = torch.empty(ops.logits_ce_bwd_workspace(Mt, 8192), dtype=torch.uint8, device=DEV)
     add("head CE bwd slab       M=8192 N=8192 K=768", 2.0 * Mt * slab * d,
-        lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias))
+        lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws))
     dH = torch.empty(Mt, d, device=DEV)
     add("head dgrad slab        M=8192 N=768 K=8192 (B kmajor)", 2.0 * Mt * slab * d, lambda: ops.gemm(dl, wv[:slab], dH, b_kmajor=True))
     dW = torch.empty(slab, d, device=DEV)
@@ -83,6 +84,33 @@ def main():
         add(f"ref  square NT         {n}^3", 2.0 * n ** 3, lambda: ops.gemm(a, b, c))
     for name, ms, tf in rows:
         print(f"{name:60s} {ms * 1e3:9.1f} us  {tf:7.1f} TFLOP/s")
+    # A/B of the row-major kernels in one process, interleaved: register-staged / 128x128 ring / 256x128 ring
+    import ctypes
+    lib = _lib.load()
+    lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
+    lib.capdecdbg_gemm_mode.restype = None
+    a8, b8 = r(8192, 8192), r(8192, 8192)
+    c8 = torch.empty(8192, 8192, device=DEV, dtype=BF)
+    cases = {
+        "KV proj 58624x1536x768": (2.0 * M * 2 * d * d, lambda: ops.gemm(x_all, w_kv, kv, bias=bias_kv)),
+        "logits+CE fwd 8192x50260x768": (2.0 * Mt * V * d, lambda: ops.logits_ce_fwd(x_t, wv, bias_v, labels, B, L, lse, amax, ls, cr, ws)),
+        "CE bwd slab 8192x8192x768": (2.0 * Mt * slab * d, lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws)),
+        "linear1 8192x2048x768": (2.0 * Mt * ff * d, lambda: ops.gemm(x_t, w1, a1, bias=bias_ff, act=_lib.ACT_RELU, drop=drop)),
+        "square 8192^3": (2.0 * 8192 ** 3, lambda: ops.gemm(a8, b8, c8)),
+    }
+    t_with = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws), 20)
+    t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
+    print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
+    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256")
+    for name, (fl, fn) in cases.items():
+        res = {1: [], 2: [], 3: []}
+        for _ in range(5):
+            for mode in (1, 2, 3):
+                lib.capdecdbg_gemm_mode(mode)
+                res[mode].append(fl / timeit(fn, 5) / 1e9)
+        lib.capdecdbg_gemm_mode(0)
+        med = {m: sorted(v)[2] for m, v in res.items()}
+        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f}")
 
 
 if __name__ == "__main__":
