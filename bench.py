@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-greedy", action="store_true")
     ap.add_argument("--greedy-images", type=int, default=4096)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--vocab-slab", type=int, default=0, help="vocabulary columns per backward slab (0: engine default)")
     return ap.parse_args()
 
 
@@ -109,6 +110,8 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     opts = EngineOptions(compute_dtype=cdt, mask_mode=args.mask_mode, activation=args.activation,
                          scored_rows_only=not args.all_rows)
+    if args.vocab_slab:
+        opts.vocab_slab = args.vocab_slab
     torch.manual_seed(42)                                           # config.py:27,41
     model = TransformerDecoder(768, 8, 6, 2048, 0.1, 50260, n_blocks=args.n_blocks, options=opts).to(dev)
     model.train()                                                   # decoder.py:144: dropout active
@@ -146,7 +149,7 @@ def main():
         value = samples / elapsed
         # ---- roofline of the dominant kernel: the vocabulary-sized GEMMs of the fused logits+CE stage
         Mh, d, V = 32 * B, 768, 50260
-        slab = model.engine.opt.vocab_slab
+        slab = model.engine.last_slab
         flops = {"logits_ce_fwd": 2.0 * Mh * d * V,
                  "logits_ce_bwd_slab": 2.0 * Mh * d * min(slab, V),
                  "head_dgrad_slab": 2.0 * Mh * d * min(slab, V),

@@ -891,16 +891,35 @@ __global__ void ce_reduce_kernel(const float* rowloss, const int32_t* rowcorrect
 uint32_t keyed_thr(const capdec_dropout& d) { return d.p > 0.f ? dropout_threshold(d.p) : 0u; }
 
 
-// out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
-// bias gradient of one vocabulary slab: dbias[n] = sum over 64-row groups of the partial column sums
-__global__ void colpart_reduce_kernel(const float* part, int nrows, long ld, int nv, float* out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= nv) return;
-    float a = 0.f;
-    for (int r = 0; r < nrows; ++r) a += part[(long)r * ld + n];
-    out[n] = a;
+// bias gradient of one vocabulary slab: dbias[n] = sum over 64-row groups of the partial column sums.
+// A block owns 64 columns; its 16 row groups each add every 16th partial row (4 rows in flight per
+// thread), and the 16 partial results are added in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* part, int nrows, long ld, int nv, float* out) {
+    __shared__ float sh[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < nv) {
+        int r = rg;
+        for (; r + 48 < nrows; r += 64) {
+            a0 += part[(long)r * ld + n];
+            a1 += part[(long)(r + 16) * ld + n];
+            a2 += part[(long)(r + 32) * ld + n];
+            a3 += part[(long)(r + 48) * ld + n];
+        }
+        for (; r < nrows; r += 16) a0 += part[(long)r * ld + n];
+    }
+    sh[rg][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rg == 0 && n < nv) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += sh[i][c];
+        out[n] = a;
+    }
 }
 
+// out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -961,8 +980,9 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     const int nkt = (a.K + BK - 1) / BK;
     const bool plain = !a.bias && a.col_scale_n == 0 && a.act == CAPDEC_ACT_NONE && !a.drop_thr && !a.residual &&
                        a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache;
-    if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 192 && nkt >= 32) {
-        long split = 512 / tiles;
+    if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 512 && nkt >= 32) {
+        // aim at >= 3 full rounds of the 512 resident workgroups, so that the last, partly filled round costs little
+        long split = (1536 + tiles - 1) / tiles;
         if (split > 8) split = 8;
         if (split > nkt / 8) split = nkt / 8;
         const long slab = (long)a.M * a.N;
@@ -1092,7 +1112,7 @@ extern "C" int capdec_logits_ce_bwd_slab(const void* h, const void* W, const flo
     if (dbias) { a.colpart = (float*)workspace; a.ld_colpart = ldp; }
     int rc = launch_gemm<EPI_CE_BWD>(a, dtype, (hipStream_t)stream);
     if (rc || !dbias) return rc;
-    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((nv + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                        (const float*)workspace, (int)((M + 63) / 64), ldp, nv, dbias + v0);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;

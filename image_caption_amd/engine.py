@@ -51,7 +51,8 @@ class EngineOptions:
     compute_dtype: torch.dtype = torch.bfloat16   # bfloat16 = MFMA path, float32 = exact validation path
     mask_mode: str = "reference"                  # decoder.py:31-38 literally; "prefix_causal" / "none"
     activation: str = "relu"                      # decoder.py:60; "gelu" is an extension
-    vocab_slab: int = 8192                        # vocabulary columns per backward slab
+    vocab_slab: int = 0                           # vocabulary columns per backward slab; 0: as wide as dl_budget_bytes allows
+    dl_budget_bytes: int = 2 << 30                # cap on the d(logits) slab buffer (the whole vocabulary fits at batch 256)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     dropout_seed: int = 42
 
@@ -336,11 +337,18 @@ class DecoderEngine:
             return loss_sum, correct, Mh
         # ---- head backward, one vocabulary slab at a time: logits are never materialised
         gscale = grad_scale / Mh
-        slab = min(self.opt.vocab_slab, (V + 127) // 128 * 128)
+        Vpad = (V + 127) // 128 * 128
+        slab = self.opt.vocab_slab
+        if slab <= 0:
+            # the widest slab the budget allows: whole-vocabulary products fill the chip's tile rounds best
+            slab = max(1024, self.opt.dl_budget_bytes // (Mh * (2 if cdt == torch.bfloat16 else 4)) // 128 * 128)
+        slab = min((slab + 127) // 128 * 128, Vpad)
+        self.last_slab = slab
         dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev)
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
         bws = self.buf("ce_bwd_ws", (ops.logits_ce_bwd_workspace(Mh, slab),), torch.uint8, dev)
+        hws = self.buf("head_splitk_ws", (4 * Mh * d * 4,), torch.uint8, dev)
         first = True
         for v0 in range(0, V, slab):
             nv = min(slab, V - v0)
@@ -349,7 +357,7 @@ class DecoderEngine:
             with self._span("logits_ce_bwd_slab"):
                 ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
             with self._span("head_dgrad_slab"):
-                ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first)
+                ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first, workspace=hws)
             with self._span("head_wgrad_slab"):
                 ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
             first = False

@@ -56,12 +56,13 @@ def check_grads(model, ref_grads, dtype):
 
 # ---------------------------------------------------------------------------- golden: tiny, full tensors
 @pytest.mark.parametrize("dtype", [F32, BF16])
-def test_tiny_golden_logits_loss_grads(dtype):
+@pytest.mark.parametrize("slab", [0, 128])          # whole vocabulary at once / 4 slabs with a ragged last one
+def test_tiny_golden_logits_loss_grads(dtype, slab):
     g = golden("tiny.npz")
     sh = TINY
     sd = helpers.make_state_dict(sh, seed=101)
     img, sos, cap, labels = helpers.make_embeddings(sh, seed=202)
-    model = make_model(sh, sd, dtype)
+    model = make_model(sh, sd, dtype, vocab_slab=slab)
     model.train()
     x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
     # (1) the reference's forward: logits for all rows
@@ -85,13 +86,13 @@ def test_tiny_golden_logits_loss_grads(dtype):
     check_grads(model, ref_grads, dtype)
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_default_b8_golden(dtype):
+@pytest.mark.parametrize("dtype,slab", [(F32, 0), (BF16, 0), (BF16, 8192)])
+def test_default_b8_golden(dtype, slab):
     g = golden("default_b8.npz")
     sh = DEFAULT_B8
     sd = helpers.make_state_dict(sh, seed=303)
     img, sos, cap, labels = helpers.make_embeddings(sh, seed=404)
-    model = make_model(sh, sd, dtype)
+    model = make_model(sh, sd, dtype, vocab_slab=slab)
     x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
     with torch.no_grad():
         logits = model(x, x)

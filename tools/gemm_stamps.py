@@ -38,7 +38,48 @@ def run(name, M, N, K, **kw):
           f"  epilogue {d[:,2].median():8.0f}  wg total {(s[:,3]-s[:,0]).median():8.0f}  kernel span {span:10.0f} ticks")
 
 
+def stamp_call(name, fn, ntiles, iters):
+    """Stamps of any library call that launches exactly one GEMM-class kernel of `ntiles` workgroups."""
+    st = torch.zeros(ntiles * 4, dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    lib.capdecdbg_gemm_stamps(st.data_ptr())
+    fn()
+    torch.cuda.synchronize()
+    lib.capdecdbg_gemm_stamps(None)
+    s = st.view(ntiles, 4).double().cpu()
+    d = s[:, 1:] - s[:, :-1]
+    span = (s[:, 3].max() - s[:, 0].min()).item()
+    print(f"{name:42s} tiles {ntiles:6d}  prologue {d[:,0].median():8.0f}  mainloop {d[:,1].median():8.0f} ({d[:,1].median()/iters:6.0f}/iter)"
+          f"  epilogue {d[:,2].median():8.0f}  wg total {(s[:,3]-s[:,0]).median():8.0f}  kernel span {span:10.0f} ticks")
+
+
+def vocabulary_cases():
+    B, L, d, V = 256, 32, 768, 50260
+    Mt = B * L
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(Mt, d, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(V, d, device=DEV, generator=g) * 0.03).to(torch.bfloat16)
+    bias = torch.zeros(V, device=DEV)
+    labels = torch.randint(0, V, (B, L), device=DEV, generator=g)
+    ws = torch.empty(ops.logits_ce_workspace(Mt, V), dtype=torch.uint8, device=DEV)
+    lse, amax = torch.empty(Mt, device=DEV), torch.empty(Mt, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    stamp_call("logits+CE fwd 8192x50260x768", lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws),
+               (Mt // 128) * ((V + 127) // 128), d // 32)
+    slab = 8192
+    dl = torch.empty(Mt, slab, device=DEV, dtype=torch.bfloat16)
+    dbias = torch.zeros(V, device=DEV)
+    bws = torch.empty(ops.logits_ce_bwd_workspace(Mt, slab), dtype=torch.uint8, device=DEV)
+    stamp_call("CE bwd slab 8192x8192x768", lambda: ops.logits_ce_bwd_slab(x, w, bias, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws),
+               (Mt // 128) * (slab // 128), d // 32)
+    dW = torch.empty(slab, d, device=DEV)
+    stamp_call("slab wgrad 8192x768x8192 (A,B kmajor)", lambda: ops.gemm(dl, x, dW, a_kmajor=True, b_kmajor=True), (slab // 128) * 6, slab // 64)
+
+
 if __name__ == "__main__":
+    vocabulary_cases()
     bias = torch.zeros(4096, device=DEV)
     run("KV proj 58624x1536x768 (bias)", 58624, 1536, 768, bias=bias[:1536])
     run("square 4096^3", 4096, 4096, 4096)
