@@ -47,11 +47,13 @@ struct GemmArgs {
     void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
     // cross-entropy epilogues
     const int64_t* labels; int ce_B, ce_L; int ce_col0;
-    float* pmax; float* psum; float* psec; int* parg; float* zlabel; int np;
+    f32x4* part4;                    // CE forward partials [np slots][M rows] of {max, sum exp(z-max), second max, argmax bits}
+    float* zlabel; int np; int want_sec;
+    int fast_epi;                    // STD: bias/scale/relu/dropout only, vector-aligned output (see epilogue_std_fast)
     const float* lse; float gscale; int store_cols;
     float* colpart; long ld_colpart;  // CE backward: per-(64-row group) column sums, [ceil(M/64)][ld_colpart]
     int split_k; long split_stride;    // split-K: blockIdx.y owns a K range and writes slab C + y*split_stride
-    unsigned long long* stamps;      // diagnostic: 4 clock stamps per workgroup, NULL in normal use
+    unsigned long long* stamps;      // diagnostic: 8 clock stamps per workgroup, NULL in normal use
 };
 
 // ------------------------------------------------------------------ tile order
@@ -233,12 +235,10 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
     const int nvalid = min(4, p.N - n);                    // <= 0: this lane owns no column
     const bool full = nvalid == 4;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {1.f, 1.f, 1.f, 1.f};
+    f32x4 scale4 = {1.f, 1.f, 1.f, 1.f};                   // the tile already holds acc + bias
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (p.bias && e < nvalid) bias4[e] = p.bias[n + e];
+    for (int e = 0; e < 4; ++e)
         if (n + e < p.col_scale_n) scale4[e] = p.col_scale;
-    }
     const bool vec_c = full && (p.ldc & 3) == 0;
     const bool vec_r = full && (p.ldr & 3) == 0;
     const bool vec_g = full && (p.ldg & 3) == 0;
@@ -248,7 +248,7 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
     auto finish_row = [&](int it, f32x4 a, f32x4 res, f32x4 gat, f32x4 cin) {
         const long m = (long)mw + it * 4 + g;
         if (m >= p.M || nvalid <= 0) return;
-        f32x4 x = (a + bias4) * scale4;
+        f32x4 x = a * scale4;
         const f32x4 pre = x;
         if (p.act == CAPDEC_ACT_GELU) {
 #pragma unroll
@@ -344,117 +344,195 @@ __device__ __forceinline__ int row_label(const GemmArgs& p, long m) {
     return (int)p.labels[b * p.ce_L + l];
 }
 
-// Row constants of the cross-entropy epilogues (label, lse) are fetched once per wave,
-// one row per lane, and parked in the 4 pad columns of the wave's LDS tile, so that the
-// row loops below contain no global load (and so never wait for their own stores).
-__device__ __forceinline__ void stage_row_consts(const GemmArgs& p, float* cs, int mw, int lane, int col0, bool want_lse) {
-    const long m = (long)mw + lane;
-    int lab = -1;
-    float lse = 0.f;
-    if (m < p.M) {
-        if (p.labels) lab = row_label(p, m) - col0;
-        if (want_lse) lse = p.lse[m];
-    }
-    cs[lane * CS_LD + 64] = __int_as_float(lab);
-    cs[lane * CS_LD + 65] = lse;
-}
+constexpr float LOG2E = 1.4426950408889634f;
 
-// per (row, 64-column slot): max, second max, argmax, sum exp(z - max); the label's logit.
-// One ROW per lane: the wave's 64x64 tile (bias already added, columns past N = -inf) is read
-// back row-wise (row stride 68 floats puts 16 consecutive rows on 16 different 16-B bank slots,
-// so the ds_read_b128 are conflict-free), and the whole reduction over the 64 columns stays
-// inside the lane -- no cross-lane traffic, no global loads, no bounds checks.
+// per (row, 64-column slot): max, argmax, sum exp(z - max) (and the second max when asked for); the
+// label's logit.  One ROW per lane: the wave's 64x64 tile (bias already added, columns past N = -inf)
+// is read back row-wise (row stride 68 floats puts 16 consecutive rows on 16 different 16-B bank slots,
+// so the ds_read_b128 are conflict-free), and the whole reduction over the 64 columns stays inside the
+// lane -- no cross-lane traffic, no global loads, no bounds checks.  The maximum is tracked per 4-column
+// chunk (5 VALU ops per 4 columns) and the winning column is located inside the winning chunk afterwards.
+// The four results of a row go out as one 16-byte store, rows contiguous across lanes.
 __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, int mw, int nw, int slot, int lane) {
     const long m = (long)mw + lane;
     const bool live = m < p.M;
-    int lab = -1;
-    if (live && p.labels) lab = row_label(p, m) - nw;       // column of the label inside this slot, if 0..63
     const float* row = cs + lane * CS_LD;
-    float m1 = -INFINITY, m2 = -INFINITY, zl = 0.f;
-    int a1 = 0x7fffffff;
+    float m1 = -INFINITY;
+    int ci = 0;
 #pragma unroll
     for (int c4 = 0; c4 < 16; ++c4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+        const float cm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        const bool gt = cm > m1;                             // strict: the lowest chunk wins a tie
+        ci = gt ? c4 : ci;
+        m1 = gt ? cm : m1;
+    }
+    const f32x4 w = *reinterpret_cast<const f32x4*>(row + ci * 4);
+    const int a1 = nw + ci * 4 + (w[0] == m1 ? 0 : (w[1] == m1 ? 1 : (w[2] == m1 ? 2 : 3)));
+    float m2 = -INFINITY;
+    if (p.want_sec) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c4 * 4 + e;
-            const float z = v[e];
-            const bool gt = z > m1;                          // strict: the lowest index wins a tie
-            m2 = gt ? m1 : fmaxf(m2, z);
-            a1 = gt ? nw + c : a1;
-            m1 = gt ? z : m1;
-            zl = c == lab ? z : zl;
+        for (int c4 = 0; c4 < 16; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m2 = fmaxf(m2, nw + c4 * 4 + e == a1 ? -INFINITY : v[e]);
         }
     }
     float sum = 0.f;
-    const float mref = m1 > -INFINITY ? m1 : 0.f;
+    const float nref = m1 > -INFINITY ? -m1 * LOG2E : 0.f;
 #pragma unroll
     for (int c4 = 0; c4 < 16; ++c4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum += __expf(v[e] - mref);
+        for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, nref));
     }
     if (live) {
-        const long o = m * p.np + slot;
-        p.pmax[o] = m1; p.psec[o] = m2; p.parg[o] = a1; p.psum[o] = sum;
-        if (lab >= 0 && lab < 64) p.zlabel[m] = zl;
+        p.part4[(long)slot * p.M + m] = f32x4{m1, sum, m2, __int_as_float(a1)};
+        if (p.labels) {
+            const int lab = row_label(p, m) - nw;            // column of the label inside this slot, if 0..63
+            if (lab >= 0 && lab < 64) p.zlabel[m] = row[lab];
+        }
     }
 }
 
-// dl = (softmax - onehot) * gscale for one vocabulary slab (tile holds z = logits incl. bias; -inf past N)
+// dl = (softmax - onehot) * gscale for one vocabulary slab (tile holds z = logits incl. bias; -inf past N).
+// A lane owns W consecutive columns (W = 8 bf16 or 4 f32: one 16-byte store per row) of the rows
+// it*RPI + lane/(64/W).  exp(z - lse) is one fma + one v_exp; the one-hot is applied by the single lane
+// that owns the label's column.
+template <int W, typename TO>
 __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, int mw, int nw, int lane) {
-    const int c4 = (lane & 15) * 4, g = lane >> 4;
-    const int n = nw + c4;
-    const int nvalid = min(4, p.N - n);
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    stage_row_consts(p, cs, mw, lane, p.ce_col0, true);
+    constexpr int LPR = 64 / W, RPI = 64 / LPR;              // lanes per row, rows per iteration
+    const int c = (lane % LPR) * W, g = lane / LPR;
+    const int n = nw + c;
+    float csum[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) csum[e] = 0.f;
+    {   // row constants, one row per lane, parked in the pad columns: label column (slab-relative), -lse*log2(e)
+        const long m = (long)mw + lane;
+        int lab = -1;
+        float nl = 0.f;
+        if (m < p.M) { lab = row_label(p, m) - p.ce_col0; nl = -p.lse[m] * LOG2E; }
+        cs[lane * CS_LD + 64] = __int_as_float(lab);
+        cs[lane * CS_LD + 65] = nl;
+    }
+    TO* C = (TO*)p.C;
 #pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + g;
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + g;
         const long m = (long)mw + row;
         if (m >= p.M || n >= p.store_cols) continue;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c4);
-        const int lab = __float_as_int(cs[row * CS_LD + 64]);
-        const float lse = cs[row * CS_LD + 65];
-        float v[4];
+        const float* src = cs + row * CS_LD;
+        const int lab = __float_as_int(src[64]) - n;
+        const float nl = src[65];
+        float v[W];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = (__expf(a[e] - lse) - (n + e == lab ? 1.f : 0.f)) * p.gscale;      // exp(-inf) = 0 past N
-            csum[e] += v[e];
+        for (int q = 0; q < W / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = __builtin_amdgcn_exp2f(fmaf(a[e], LOG2E, nl));      // exp2(-inf) = 0 past N
         }
-        store4_any(p.C, m * p.ldc + n, p.out_dtype, true, 4, v);
+        if ((unsigned)lab < (unsigned)W) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] -= e == lab ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) { v[e] *= p.gscale; csum[e] += v[e]; }
+        if constexpr (sizeof(TO) == 2) {
+            if constexpr (W == 8) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x8*>(C + m * p.ldc + n) = o;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x4*>(C + m * p.ldc + n) = o;
+            }
+        } else {
+            static_assert(W == 4, "f32 rows go out 4 columns per lane");
+            *reinterpret_cast<f32x4*>(C + m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+        }
     }
     if (p.colpart) {
         // column sums of this wave's 64 rows -> one row of the partial buffer (plain 16-B stores;
         // atomics on the bias gradient would collide 128-fold per column)
-        f32x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float s = csum[e];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            t[e] = s;
+        for (int e = 0; e < W; ++e) {
+            float t = csum[e];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            csum[e] = t;
         }
         // a wave whose 64 rows all lie past M owns no row of the [ceil(M/64)][ld] partial buffer
-        if (lane < 16 && n < p.store_cols && mw < p.M) *reinterpret_cast<f32x4*>(p.colpart + (long)(mw >> 6) * p.ld_colpart + n) = t;
+        if (lane < LPR && n < p.store_cols && mw < p.M) {
+            float* dst = p.colpart + (long)(mw >> 6) * p.ld_colpart + n;
+#pragma unroll
+            for (int q = 0; q < W / 4; ++q)
+                *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{csum[4 * q], csum[4 * q + 1], csum[4 * q + 2], csum[4 * q + 3]};
+        }
     }
 }
 
-// Accumulators -> the wave's LDS tile.  A lane holds C[row = 4*(lane>>4) + r][col = lane & 15] of
-// each 16x16 tile, i.e. only 4 distinct columns: for the cross-entropy epilogues the column bias is
-// added here (and columns past N become -inf, so they never win a max and add exp(-inf) = 0), which
-// leaves their row loops free of bias loads and bounds checks.
-template <int EPI>
-__device__ __forceinline__ void stage_acc(const GemmArgs& p, char* smem, const f32x4 (&acc)[4][4], int n0, int wave, int lane) {
-    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
-    float cb[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) {
+// The common forward epilogue, straight-line: (acc + bias) * column scale, ReLU, dropout, one 16-byte
+// store per row and lane (W = 8 bf16 or 4 f32 columns).  The host selects it when nothing else is asked
+// for and N, ldc and the base of C keep every lane's W columns aligned and either all inside N or all outside.
+template <int W, typename TO>
+__device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
+    constexpr int LPR = 64 / W, RPI = 64 / LPR;
+    const int c = (lane % LPR) * W, g = lane / LPR;
+    const int n = nw + c;
+    if (n >= p.N) return;
+    float sc[W];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + (wave & 1) * 64 + j * 16 + (lane & 15);
-            cb[j] = n < p.N ? (p.bias ? p.bias[n] : 0.f) : -INFINITY;
+    for (int e = 0; e < W; ++e) sc[e] = n + e < p.col_scale_n ? p.col_scale : 1.f;
+    const float relu_floor = p.act == CAPDEC_ACT_RELU ? 0.f : -INFINITY;
+    TO* C = (TO*)p.C;
+#pragma unroll 2
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + g;
+        const long m = (long)mw + row;
+        if (m >= p.M) continue;
+        float v[W];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(a[e] * sc[4 * q + e], relu_floor);
+        }
+        if (p.drop_thr) {
+            const uint32_t base = (uint32_t)(m * p.N + n);
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = dropout_keep(p.drop_k0, p.drop_k1, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+        }
+        if constexpr (sizeof(TO) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(C + m * p.ldc + n) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(C + m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
         }
     }
+}
+
+// Column constants of a wave's tile, in accumulator layout (a lane holds only 4 distinct columns):
+// the bias, and for the cross-entropy epilogues -inf past N (such columns never win a max and add
+// exp(-inf) = 0), which leaves the row loops free of bias loads and bounds checks.
+template <int EPI>
+__device__ __forceinline__ void load_col_consts(const GemmArgs& p, int n0, int wave, int lane, float (&cb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+        const float past = (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) ? -INFINITY : 0.f;
+        cb[j] = n < p.N ? (p.bias ? p.bias[n] : 0.f) : past;
+    }
+}
+
+// Accumulators (+ column constants) -> the wave's LDS tile.  A lane holds
+// C[row = 4*(lane>>4) + r][col = lane & 15] of each 16x16 tile.
+__device__ __forceinline__ void stage_acc(char* smem, const f32x4 (*acc)[4], const float (&cb)[4], int wave, int lane) {
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -466,15 +544,25 @@ __device__ __forceinline__ void stage_acc(const GemmArgs& p, char* smem, const f
     __builtin_amdgcn_wave_barrier();
 }
 
+// the wave's staged 64x64 tile has its corner at (mw, nw); slot = index of its 64-column group
+template <int EPI>
+__device__ __forceinline__ void run_epilogue_at(const GemmArgs& p, float* cs, int mw, int nw, int slot, int lane) {
+    if constexpr (EPI == EPI_STD) {
+        if (p.fast_epi == 8) epilogue_std_fast<8, bf16_t>(p, cs, mw, nw, lane);
+        else if (p.fast_epi == 4) epilogue_std_fast<4, float>(p, cs, mw, nw, lane);
+        else epilogue_std<false>(p, cs, mw, nw, lane);
+    } else if constexpr (EPI == EPI_STD_SIDE) epilogue_std<true>(p, cs, mw, nw, lane);
+    else if constexpr (EPI == EPI_CE_FWD) epilogue_ce_fwd(p, cs, mw, nw, slot, lane);
+    else {
+        if (p.fast_epi == 8) epilogue_ce_bwd<8, bf16_t>(p, cs, mw, nw, lane);
+        else if (p.out_dtype == CAPDEC_BF16) epilogue_ce_bwd<4, bf16_t>(p, cs, mw, nw, lane);
+        else epilogue_ce_bwd<4, float>(p, cs, mw, nw, lane);
+    }
+}
 template <int EPI>
 __device__ __forceinline__ void run_epilogue(const GemmArgs& p, char* smem, int m0, int n0, int tile_n, int wave, int lane) {
     const int wr = wave >> 1, wc = wave & 1;
-    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
-    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
-    if constexpr (EPI == EPI_STD) epilogue_std<false>(p, cs, mw, nw, lane);
-    else if constexpr (EPI == EPI_STD_SIDE) epilogue_std<true>(p, cs, mw, nw, lane);
-    else if constexpr (EPI == EPI_CE_FWD) epilogue_ce_fwd(p, cs, mw, nw, tile_n * 2 + wc, lane);
-    else epilogue_ce_bwd(p, cs, mw, nw, lane);
+    run_epilogue_at<EPI>(p, reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES), m0 + wr * 64, n0 + wc * 64, tile_n * 2 + wc, lane);
 }
 
 // ------------------------------------------------------------------ bf16 MFMA kernel
@@ -513,7 +601,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
         p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
     }
     const int kb = kt0 * BK;
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
     // One k-tile of register prefetch: the loads of tile t+1 are issued before tile t is
     // multiplied out of LDS and written to the other LDS stage after it.  (A second register
     // set was tried: hipcc's wait-count insertion then drains every load at each LDS write,
@@ -525,7 +613,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
     stash_tile<A_TR>(smem, ta, ra, kb, p.K);
     stash_tile<B_TR>(smem + TILE_BYTES, tb, rb, kb, p.K);
     __syncthreads();
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
 
     for (int kt = 0; kt < nk; ++kt) {
         const char* sA = smem + (kt & 1) * STAGE_BYTES;
@@ -557,10 +645,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-    stage_acc<EPI>(p, smem, acc, n0, wave, lane);
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+    float cb[4];
+    load_col_consts<EPI>(p, n0, wave, lane, cb);
+    stage_acc(smem, acc, cb, wave, lane);
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------ bf16 MFMA kernel, LDS-DMA ring
@@ -599,40 +689,56 @@ __device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int pie
     }
 }
 
-// NJ pieces per wave; piece j of wave w is image piece NW*j + w
-template <bool TR, int NJ, int NW>
-__device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned (&off)[2], int k0, char* tile, int wave) {
+// buffer descriptor of an operand's k-tile starting at k0 (reads past the operand's end return 0)
+template <bool TR>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const OperandView& v, int k0) {
     const long adv = TR ? (long)k0 * v.ld : (long)k0;
     const long rem = (v.remaining - adv) * 2;
     const int hi = (int)(rem >> 32);
     const unsigned lo = (unsigned)rem;
     const unsigned rec = hi < 0 ? 0u : (hi > 0 ? 0xFFFFFFF0u : (lo > 0xFFFFFFF0u ? 0xFFFFFFF0u : lo));
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)rec, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(v.base + adv), 0, (int)rec, 0x00020000);
+}
+// one 1-KiB piece: lane l's 16 bytes land at dst + 16*l
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned off, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+}
+// NJ pieces per wave; piece j of wave w is image piece NW*j + w
+template <bool TR, int NJ, int NW>
+__device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned* off, int k0, char* tile, int wave) {
+    __amdgpu_buffer_rsrc_t rs = dma_rsrc<TR>(v, k0);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, tile + (NW * j + wave) * 1024), 16, off[j], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) dma_piece(rs, off[j], tile + (NW * j + wave) * 1024);
 }
 
-// WM = 2: 128x128 tile, 4 waves, two workgroups per CU.  WM = 4: 256x128 tile, 8 waves, one
-// workgroup per CU: the B panel is shared by twice as many MFMAs, which cuts the L2 -> LDS
-// traffic per FLOP by a quarter (the 128x128 ring is L2-bandwidth bound on the K=768 products).
-// Row-major A only reaches WM = 4 (a reduction-major A image has 128-column rows).
-template <int WM> struct DmaGeo {
+// Geometry <WM, TI, NST>: 2*WM waves in a WM x 2 grid, each wave TI x 4 MFMA tiles (16*TI rows x 64
+// columns), NST ring stages.
+//   <2,4,4>  128x128, 4 waves, 2 workgroups/CU: small grids and reduction-major operands
+//   <2,8,3>  256x128, 4 waves of 128x64, 2 workgroups/CU: per MFMA a quarter fewer DMA pieces and LDS
+//            reads than 128x128 (whose 16 KiB per 32-deep step needs the CU's whole 64 B/clk fill path),
+//            and the co-resident workgroup's main loop covers this one's epilogue
+//   <4,4,4>  256x128, 8 waves of 64x64, 1 workgroup/CU
+// A row-major only beyond 128 rows (a reduction-major A image has 128-column rows).
+template <int WM, int TI, int NST> struct DmaGeo {
     static constexpr int NW = 2 * WM;                       // waves
-    static constexpr int BMV = 64 * WM;                     // tile rows
+    static constexpr int WROWS = 16 * TI;                   // rows per wave
+    static constexpr int BMV = WM * WROWS;                  // tile rows
     static constexpr int A_BYTES = BMV * 64;                // one 32-deep A image
     static constexpr int STAGE = A_BYTES + DTILE_BYTES;
+    static constexpr int NJA = A_BYTES / 1024 / NW;         // A pieces per wave
     static constexpr int NJB = 8 / NW;                      // B pieces per wave
-    static constexpr int RING = DSTAGES * STAGE;
+    static constexpr int INFLIGHT = (NST - 2) * (NJA + NJB);// DMA instructions that may stay outstanding at the wait
+    static constexpr int RING = NST * STAGE;
     static constexpr int CSTAGE = NW * CS_WAVE_BYTES;
     static constexpr int LDS = RING > CSTAGE ? RING : CSTAGE;
+    static constexpr int WG_PER_CU = 2 * LDS <= 160 * 1024 && NW == 4 ? 2 : 1;
 };
 
-template <bool A_TR, bool B_TR, int EPI, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_bf16_dma_kernel(GemmArgs p) {
+template <bool A_TR, bool B_TR, int EPI, int WM, int TI, int NST>
+__global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void gemm_bf16_dma_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = DmaGeo<WM>;
-    static_assert(WM == 2 || !A_TR, "256-row tiles need a row-major A");
+    using G = DmaGeo<WM, TI, NST>;
+    static_assert(G::BMV == 128 || !A_TR, "tiles taller than 128 rows need a row-major A");
     const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + BN - 1) / BN;
     int tile_m, tile_n;
     map_tile(tm, tn, tile_m, tile_n);
@@ -648,56 +754,84 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_bf16_dma_kerne
     if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
     else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
     vb.ld = p.ldb; vb.rows_left = p.N - n0;
-    const unsigned offa[2] = {dma_src_offset<A_TR>(va, wave, lane), dma_src_offset<A_TR>(va, G::NW + wave, lane)};
-    const unsigned offb[2] = {dma_src_offset<B_TR>(vb, wave, lane), G::NJB > 1 ? dma_src_offset<B_TR>(vb, G::NW + wave, lane) : 0u};
-
-    f32x4 acc[4][4];
+    unsigned offa[G::NJA], offb[G::NJB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < G::NJA; ++j) offa[j] = dma_src_offset<A_TR>(va, G::NW * j + wave, lane);
+#pragma unroll
+    for (int j = 0; j < G::NJB; ++j) offb[j] = dma_src_offset<B_TR>(vb, G::NW * j + wave, lane);
+
+    float cb[4];                             // column constants of the epilogue: fetched now, used after the main loop
+    load_col_consts<EPI>(p, n0, wave, lane, cb);
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / DBK;
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
     // a stage index past the last k-tile still issues its (harmless) loads, so that the
     // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
-    auto dma_stage = [&](int kt) {
-        char* st = smem + (kt & (DSTAGES - 1)) * G::STAGE;
-        dma_tile<A_TR, 2, G::NW>(va, offa, kt * DBK, st, wave);
+    auto dma_stage = [&](int kt, int slot) {
+        char* st = smem + slot * G::STAGE;
+        dma_tile<A_TR, G::NJA, G::NW>(va, offa, kt * DBK, st, wave);
         dma_tile<B_TR, G::NJB, G::NW>(vb, offb, kt * DBK, st + G::A_BYTES, wave);
     };
-    dma_stage(0);
-    dma_stage(1);
-    dma_stage(2);
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // three stages (2 + NJB DMA instructions each) of this wave are outstanding; all but the
-        // two youngest stages = stage kt
-        if constexpr (G::NJB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();        // every wave's share of stage kt has landed; stage kt-1 is no longer read
-        dma_stage(kt + 3);                   // refill the stage that was read in iteration kt-1
-        const char* sA = smem + (kt & (DSTAGES - 1)) * G::STAGE;
-        const char* sB = sA + G::A_BYTES;
-        bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = dread_frag<A_TR>(sA, wr * 64 + i * 16, lane);
+    for (int s = 0; s < NST - 1; ++s) dma_stage(s, s);
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+
+    int rslot = 0, wslot = NST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // NST-1 stages of this wave are outstanding; all but the NST-2 youngest = stage kt
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();        // every wave's share of stage kt has landed; stage kt-1 is no longer read
+        const char* sA = smem + rslot * G::STAGE;
+        const char* sB = sA + G::A_BYTES;
+        // all fragment reads of the step go out first, then the refill DMAs (whose issue covers the LDS
+        // latency), then the MFMAs, each waiting only for the fragments it consumes
+        bf16x8 af[TI], bfr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = dread_frag<B_TR>(sB, wc * 64 + j * 16, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i) af[i] = dread_frag<A_TR>(sA, wr * G::WROWS + i * 16, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // refill of the stage that was read in iteration kt-1: one DMA piece after each row of MFMAs, so that
+        // its issue time is covered by matrix work instead of delaying the first MFMA of the step
+        char* wst = smem + wslot * G::STAGE;
+        const __amdgpu_buffer_rsrc_t rsa = dma_rsrc<A_TR>(va, (kt + NST - 1) * DBK);
+        const __amdgpu_buffer_rsrc_t rsb = dma_rsrc<B_TR>(vb, (kt + NST - 1) * DBK);
+        rslot = rslot + 1 == NST ? 0 : rslot + 1;
+        wslot = wslot + 1 == NST ? 0 : wslot + 1;
+        constexpr int NP = G::NJA + G::NJB;
+        static_assert(NP <= TI, "one DMA piece per MFMA row at most");
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (i < NP) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < G::NJA) dma_piece(rsa, offa[i], wst + (G::NW * i + wave) * 1024);
+                else dma_piece(rsb, offb[i - G::NJA], wst + G::A_BYTES + (G::NW * (i - G::NJA) + wave) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // trailing refills must land before LDS is reused
     __syncthreads();
 
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-    stage_acc<EPI>(p, smem, acc, n0, wave, lane);
-    run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+    // the wave's rows go through its private 64x64 LDS tile, 64 rows at a time
+#pragma unroll
+    for (int h = 0; h < TI / 4; ++h) {
+        stage_acc(smem, acc + 4 * h, cb, wave, lane);
+        if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 3 + 2 * h] = __builtin_amdgcn_s_memtime();
+        run_epilogue_at<EPI>(p, reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES), m0 + wr * G::WROWS + h * 64, n0 + wc * 64,
+                             tile_n * 2 + wc, lane);
+        if (p.stamps && tid == 0 && h == 0) p.stamps[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
+    }
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------ exact-f32 kernel (validation mode)
@@ -759,8 +893,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         for (int j = 0; j < 8; ++j) {
             const int mm = ty * 8 + i, nn = tx * 8 + j;
             const int w = (mm >> 6) * 2 + (nn >> 6);
-            float cbias = 0.f;
-            if constexpr (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) cbias = n0 + nn < p.N ? (p.bias ? p.bias[n0 + nn] : 0.f) : -INFINITY;
+            const float past = (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) ? -INFINITY : 0.f;
+            const float cbias = n0 + nn < p.N ? (p.bias ? p.bias[n0 + nn] : 0.f) : past;
             reinterpret_cast<float*>(smem + w * CS_WAVE_BYTES)[(mm & 63) * CS_LD + (nn & 63)] = acc[i][j] + cbias;
         }
     __syncthreads();
@@ -783,34 +917,45 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
     if (in_dtype == CAPDEC_BF16) {
         CAPDEC_CHECK((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm(bf16): lda/ldb must be multiples of 8 (got %ld, %ld)", a.lda, a.ldb);
         CAPDEC_CHECK(aligned16(a.A) && aligned16(a.B), "gemm(bf16): A/B must be 16-byte aligned");
+        using G128 = DmaGeo<2, 4, 4>;
 #define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
     do {                                                                                               \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI, 2>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, DmaGeo<2>::LDS);     \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI, 2, 4, 4>,         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, G128::LDS);    \
             attr_set = true;                                                                           \
         }                                                                                              \
-        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI, 2>), grid, block, DmaGeo<2>::LDS, st, a); \
+        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI, 2, 4, 4>), grid, block, G128::LDS, st, a); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);       \
     } while (0)
         // the DMA ring wins on row-major x row-major operands; reduction-major operands (transposing
         // LDS reads, two per fragment) and split-K stay on the register-staged kernel
         const bool use_dma = (a.K % DBK) == 0 && a.K >= DBK && !a.a_kmajor && !a.b_kmajor && a.split_k <= 1 && g_gemm_mode != 1;
         const long big_tiles = (long)((a.M + 255) / 256) * tn;
-        // 256-row tiles pay off only when the main loop dominates (deep K); with K = 768 the exposed epilogue of
-        // the single resident workgroup costs more than the saved L2 traffic (A/B in tools/gemm_bench.py)
-        const bool use_big = use_dma && ((big_tiles >= 512 && a.K >= 2048 && g_gemm_mode != 2) || g_gemm_mode == 3);
-        if (use_big) {
+        // 256-row tiles: 4 waves of 128x64, two workgroups per CU, whenever they still give every CU work
+        const bool use_tall = use_dma && ((big_tiles >= 256 && g_gemm_mode == 0) || g_gemm_mode == 4);
+        const bool use_big = use_dma && g_gemm_mode == 3;       // diagnostic: 8 waves, one workgroup per CU
+        if (use_tall) {
+            using G = DmaGeo<2, 8, 3>;
+            static bool tall_attr = false;
+            if (!tall_attr) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 2, 8, 3>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+                tall_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 2, 8, 3>), dim3((unsigned)big_tiles), dim3(256), G::LDS, st, a);
+        } else if (use_big) {
+            using G = DmaGeo<4, 4, 4>;
             static bool big_attr = false;
             if (!big_attr) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, DmaGeo<4>::LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 4, 4, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
                 big_attr = true;
             }
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 4>), dim3((unsigned)big_tiles), dim3(512), DmaGeo<4>::LDS, st, a);
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 4, 4, 4>), dim3((unsigned)big_tiles), dim3(512), G::LDS, st, a);
         } else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
         else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
         else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
@@ -829,34 +974,42 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ CE finalize kernels
-// one wave per row: fold the per-slot partials into lse / argmax / margin / row loss
-__global__ void ce_finalize_kernel(const float* pmax, const float* psum, const float* psec, const int* parg,
-                                   const float* zlabel, const int64_t* labels, int ce_B, int ce_L, long M, int np,
-                                   float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
-                                   float* rowloss, int32_t* rowcorrect) {
-    const int lane = threadIdx.x & 63;
-    const long m = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (m >= M) return;
-    Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
-    for (int s = lane; s < np; s += 64) {
-        const long o = m * np + s;
-        top2_merge(t, pmax[o], parg[o], psec[o]);
+// Fold the per-slot partials into lse / argmax / margin / row loss.  A block owns 64 rows (one per
+// lane, so every partial read is a contiguous 1 KiB per wave); its 16 waves each fold every 16th slot
+// with an online rescaling of the sum, and wave 0 merges the 16 results in a fixed order (deterministic).
+struct RowFold { float m1; int a1; float m2; float s; };
+__device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2, float ps) {
+    if (pm > t.m1 || (pm == t.m1 && pa < t.a1)) {
+        t.s = t.s * (t.m1 > -INFINITY ? __expf(t.m1 - pm) : 0.f) + ps;
+        t.m2 = fmaxf(t.m1, p2); t.m1 = pm; t.a1 = pa;
+    } else {
+        if (pm > -INFINITY) t.s += ps * __expf(pm - t.m1);
+        t.m2 = fmaxf(t.m2, pm);
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float om1 = __shfl_xor(t.m1, o, 64), om2 = __shfl_xor(t.m2, o, 64);
-        const int oa1 = __shfl_xor(t.a1, o, 64);
-        top2_merge(t, om1, oa1, om2);
+}
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, const float* zlabel, const int64_t* labels,
+                                                           int ce_B, int ce_L, long M, int np,
+                                                           float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
+                                                           float* rowloss, int32_t* rowcorrect) {
+    __shared__ RowFold sh[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long m = (long)blockIdx.x * 64 + lane;
+    RowFold t = {-INFINITY, 0x7fffffff, -INFINITY, 0.f};
+    if (m < M) {
+        for (int sl = w; sl < np; sl += 16) {
+            const f32x4 q = part4[(long)sl * M + m];
+            fold_push(t, q[0], __float_as_int(q[3]), q[2], q[1]);
+        }
     }
-    float s = 0.f;
-    for (int sl = lane; sl < np; sl += 64) {
-        const long o = m * np + sl;
-        const float pm = pmax[o];
-        if (pm > -INFINITY) s += psum[o] * __expf(pm - t.m1);
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-        const float lse = t.m1 + logf(s);
+    sh[w][lane] = t;
+    __syncthreads();
+    if (w == 0 && m < M) {
+#pragma unroll 1
+        for (int i = 1; i < 16; ++i) {
+            const RowFold o = sh[i][lane];
+            fold_push(t, o.m1, o.a1, o.m2, o.s);
+        }
+        const float lse = t.m1 + logf(t.s);
         if (lse_out) lse_out[m] = lse;
         if (argmax_out) argmax_out[m] = t.a1;
         if (ids_out) ids_out[m] = t.a1;
@@ -990,6 +1143,7 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
             GemmArgs b = a;
             b.C = d->workspace; b.ldc = a.N; b.out_dtype = CAPDEC_F32; b.accumulate = 0;
             b.split_k = (int)split; b.split_stride = slab;
+            b.fast_epi = (a.N % 4) == 0 && ((slab * 4) % 16) == 0 && aligned16(d->workspace) ? 4 : 0;
             int rc = launch_gemm<EPI_STD>(b, d->in_dtype, (hipStream_t)stream);
             if (rc) return rc;
             const int nb = (int)((slab + 255) / 256 > 2048 ? 2048 : (slab + 255) / 256);
@@ -1001,6 +1155,13 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
             return CAPDEC_OK;
         }
     }
+    // straight-line epilogue: bias / column scale / ReLU / dropout only, every lane's 16-byte group of columns
+    // aligned and entirely inside or outside N
+    if (!a.residual && !a.accumulate && a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache &&
+        a.act != CAPDEC_ACT_GELU && aligned16(a.C)) {
+        if (a.out_dtype == CAPDEC_BF16 && (a.N % 8) == 0 && (a.ldc % 8) == 0) a.fast_epi = 8;
+        else if (a.out_dtype == CAPDEC_F32 && (a.N % 4) == 0 && (a.ldc % 4) == 0) a.fast_epi = 4;
+    }
     if (a.residual || a.accumulate || a.gate_mode != CAPDEC_GATE_NONE) return launch_gemm<EPI_STD_SIDE>(a, d->in_dtype, (hipStream_t)stream);
     return launch_gemm<EPI_STD>(a, d->in_dtype, (hipStream_t)stream);
 }
@@ -1011,14 +1172,13 @@ extern "C" long capdec_logits_ce_workspace(long M, int V) {
 }
 
 namespace {
-struct CeWs { float* pmax; float* psum; float* psec; int* parg; float* zlabel; float* rowloss; int32_t* rowcorrect; int np; };
+struct CeWs { f32x4* part4; float* zlabel; float* rowloss; int32_t* rowcorrect; int np; };
 bool carve_ce_ws(void* ws, long bytes, long M, int V, CeWs& o) {
-    if (!ws || bytes < capdec_logits_ce_workspace(M, V)) return false;
+    if (!ws || bytes < capdec_logits_ce_workspace(M, V) || ((uintptr_t)ws & 15)) return false;
     o.np = 2 * ((V + BN - 1) / BN);
-    float* f = (float*)ws;
     const long n = M * o.np;
-    o.pmax = f; o.psum = f + n; o.psec = f + 2 * n; o.parg = (int*)(f + 3 * n);
-    o.zlabel = f + 4 * n; o.rowloss = o.zlabel + M; o.rowcorrect = (int32_t*)(o.rowloss + M);
+    o.part4 = (f32x4*)ws;
+    o.zlabel = (float*)ws + 4 * n; o.rowloss = o.zlabel + M; o.rowcorrect = (int32_t*)(o.rowloss + M);
     return true;
 }
 void fill_head_args(GemmArgs& a, const void* h, const void* W, const float* bias, long M, int V, int d, long ldh, long ldw) {
@@ -1044,13 +1204,12 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
     a.C = workspace;  // unused by this epilogue
     a.labels = labels; a.ce_B = B; a.ce_L = L;
-    a.pmax = ws.pmax; a.psum = ws.psum; a.psec = ws.psec; a.parg = ws.parg; a.zlabel = ws.zlabel; a.np = ws.np;
+    a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
-    const int rows_per_block = 4;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(64 * rows_per_block), 0, st,
-                       ws.pmax, ws.psum, ws.psec, ws.parg, ws.zlabel, labels, B, L, M, ws.np,
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(1024), 0, st,
+                       ws.part4, ws.zlabel, labels, B, L, M, ws.np,
                        lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
     CAPDEC_LAUNCH_CHECK();
@@ -1072,13 +1231,12 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
     a.C = workspace;
     a.ce_B = 1; a.ce_L = 1;
-    a.pmax = ws.pmax; a.psum = ws.psum; a.psec = ws.psec; a.parg = ws.parg; a.zlabel = ws.zlabel; a.np = ws.np;
+    a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np; a.want_sec = margin != nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
-    const int rows_per_block = 4;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(64 * rows_per_block), 0, st,
-                       ws.pmax, ws.psum, ws.psec, ws.parg, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(1024), 0, st,
+                       ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
                        (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -1106,6 +1264,7 @@ extern "C" int capdec_logits_ce_bwd_slab(const void* h, const void* W, const flo
     const size_t esz = dtype == CAPDEC_BF16 ? 2 : 4;
     fill_head_args(a, h, (const char*)W + (size_t)v0 * ldw * esz, bias ? bias + v0 : nullptr, M, nv, d, ldh, ldw);
     a.C = dl; a.ldc = ld_dl; a.out_dtype = dtype; a.store_cols = (int)ld_dl;
+    if (dtype == CAPDEC_BF16 && (ld_dl % 8) == 0 && aligned16(dl)) a.fast_epi = 8;      // 8 columns = one 16-byte store per lane
     a.labels = labels; a.ce_B = B; a.ce_L = L; a.ce_col0 = v0;
     a.lse = lse; a.gscale = gscale;
     const long ldp = (long)((nv + BN - 1) / BN) * BN;

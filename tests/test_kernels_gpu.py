@@ -49,6 +49,65 @@ def test_gemm_layouts(dtype, tol, akm, bkm, M, N, K):
     close(out, ref, tol, "gemm")
 
 
+@pytest.fixture
+def gemm_mode():
+    """Forces one bf16 kernel geometry (diagnostic hook of the library); restored afterwards."""
+    import ctypes
+    lib = _lib.load()
+    lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
+    lib.capdecdbg_gemm_mode.restype = None
+    yield lib.capdecdbg_gemm_mode
+    lib.capdecdbg_gemm_mode(0)
+
+
+# 1 register-staged, 2 ring 128x128, 3 ring 256x128 (8 waves), 4 ring 256x128 (4 waves of 128x64)
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 264, 192), (1000, 72, 96), (515, 640, 768), (64, 136, 64)])
+def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(N, K, dtype=torch.bfloat16, scale=0.1, seed=32)
+    bias, res = rnd(N, seed=33), rnd(M, N, seed=34)
+    ref = A.float() @ B.float().t() + bias
+    gemm_mode(mode)
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(A, B, out, bias=bias)
+    out2 = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, B, out2, bias=bias, residual=res)
+    gemm_mode(0)
+    close(out, ref, 1.5e-2, f"mode {mode}")
+    close(out2, ref + res, 1.5e-2, f"mode {mode} + residual")
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_logits_ce_every_geometry(gemm_mode, mode):
+    B_, L, V, d = 5, 8, 1111, 64                       # 40 rows: ragged in M; 1111 columns: ragged in N
+    M = B_ * L
+    h = rnd(M, d, dtype=torch.bfloat16, seed=41)
+    w = rnd(V, d, dtype=torch.bfloat16, scale=0.3, seed=42)
+    b = rnd(V, seed=43)
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(44)).to(DEV)
+    z = h.float() @ w.float().t() + b
+    lab_rows = labels.t().reshape(-1)                  # row m = l * B + b
+    ref_lse = torch.logsumexp(z, 1)
+    ref_loss = (ref_lse - z.gather(1, lab_rows[:, None])[:, 0]).sum()
+    ref_dl = (torch.softmax(z, 1) - torch.nn.functional.one_hot(lab_rows, V)) / M
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    lse, amax = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dbias = torch.full((V,), float("nan"), device=DEV)
+    bws = torch.empty(ops.logits_ce_bwd_workspace(M, V), dtype=torch.uint8, device=DEV)
+    gemm_mode(mode)
+    ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws)
+    ops.logits_ce_bwd_slab(h, w, b, labels, B_, L, lse, 1.0 / M, 0, V, dl, dbias, bws)
+    gemm_mode(0)
+    close(lse, ref_lse, 2e-3, "lse")
+    assert abs(ls.item() - ref_loss.item()) <= 2e-3 * abs(ref_loss.item())
+    assert (amax.long() == z.argmax(1)).float().mean().item() >= 0.95     # bf16 near-ties may flip
+    close(dl[:, :V], ref_dl, 1e-2, "dl")
+    close(dbias, ref_dl.sum(0), 1e-2, "dbias")
+
+
 @pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
 def test_gemm_split_k(M, N, K, out):
     # weight-gradient shape: few output tiles, deep K; both operands reduction-major

@@ -101,16 +101,16 @@ def main():
     t_with = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws), 20)
     t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
     print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
-    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256")
+    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU)")
     for name, (fl, fn) in cases.items():
-        res = {1: [], 2: [], 3: []}
+        res = {1: [], 2: [], 3: [], 4: []}
         for _ in range(5):
-            for mode in (1, 2, 3):
+            for mode in (1, 2, 3, 4):
                 lib.capdecdbg_gemm_mode(mode)
                 res[mode].append(fl / timeit(fn, 5) / 1e9)
         lib.capdecdbg_gemm_mode(0)
         med = {m: sorted(v)[2] for m, v in res.items()}
-        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f}")
+        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f} | {med[4]:7.1f}")
 
 
 if __name__ == "__main__":

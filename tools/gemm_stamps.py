@@ -23,7 +23,7 @@ def run(name, M, N, K, **kw):
     B = (torch.randn((K, N) if bkm else (N, K), device=DEV, generator=g) * 0.03).to(torch.bfloat16)
     C = torch.empty(M, N, device=DEV, dtype=kw.pop("out", torch.bfloat16))
     ntiles = ((M + 127) // 128) * ((N + 127) // 128)
-    st = torch.zeros(ntiles * 4, dtype=torch.int64, device=DEV)
+    st = torch.zeros(ntiles * 8, dtype=torch.int64, device=DEV)
     for _ in range(2):
         ops.gemm(A, B, C, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm, **kw)
     torch.cuda.synchronize()
@@ -31,16 +31,23 @@ def run(name, M, N, K, **kw):
     ops.gemm(A, B, C, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm, **kw)
     torch.cuda.synchronize()
     lib.capdecdbg_gemm_stamps(None)
-    s = st.view(ntiles, 4).double().cpu()
+    s = st.view(ntiles, 8).double().cpu()
+    s = s[s[:, 0] > 0]                      # taller tiles launch fewer workgroups than the 128-row count
+    ntiles = s.shape[0]
+    for c in range(3, 7):                   # epilogue sub-stamps a kernel does not write: carry the previous one
+        s[:, c] = torch.where(s[:, c] > 0, s[:, c], s[:, c - 1])
+    sub = (s[:, 3:8] - s[:, 2:7]).median(0).values.tolist()
+    s = torch.cat([s[:, :3], s[:, 7:8]], 1)
     d = s[:, 1:] - s[:, :-1]
     span = (s[:, 3].max() - s[:, 0].min()).item()
-    print(f"{name:42s} tiles {ntiles:6d}  prologue {d[:,0].median():8.0f}  mainloop {d[:,1].median():8.0f} ({d[:,1].median()/((K+63)//64):6.0f}/iter)"
+    name = f"{name} [epilogue: stage {sub[0]:.0f} rows {sub[1]:.0f} stage {sub[2]:.0f} rows {sub[3]:.0f}+{sub[4]:.0f}]"
+    print(f"{name}\n    tiles {ntiles:6d}  prologue {d[:,0].median():8.0f}  mainloop {d[:,1].median():8.0f} ({d[:,1].median()/((K+63)//64):6.0f}/iter)"
           f"  epilogue {d[:,2].median():8.0f}  wg total {(s[:,3]-s[:,0]).median():8.0f}  kernel span {span:10.0f} ticks")
 
 
 def stamp_call(name, fn, ntiles, iters):
     """Stamps of any library call that launches exactly one GEMM-class kernel of `ntiles` workgroups."""
-    st = torch.zeros(ntiles * 4, dtype=torch.int64, device=DEV)
+    st = torch.zeros(ntiles * 8, dtype=torch.int64, device=DEV)
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -48,10 +55,17 @@ def stamp_call(name, fn, ntiles, iters):
     fn()
     torch.cuda.synchronize()
     lib.capdecdbg_gemm_stamps(None)
-    s = st.view(ntiles, 4).double().cpu()
+    s = st.view(ntiles, 8).double().cpu()
+    s = s[s[:, 0] > 0]                      # taller tiles launch fewer workgroups than the 128-row count
+    ntiles = s.shape[0]
+    for c in range(3, 7):                   # epilogue sub-stamps a kernel does not write: carry the previous one
+        s[:, c] = torch.where(s[:, c] > 0, s[:, c], s[:, c - 1])
+    sub = (s[:, 3:8] - s[:, 2:7]).median(0).values.tolist()
+    s = torch.cat([s[:, :3], s[:, 7:8]], 1)
     d = s[:, 1:] - s[:, :-1]
     span = (s[:, 3].max() - s[:, 0].min()).item()
-    print(f"{name:42s} tiles {ntiles:6d}  prologue {d[:,0].median():8.0f}  mainloop {d[:,1].median():8.0f} ({d[:,1].median()/iters:6.0f}/iter)"
+    name = f"{name} [epilogue: stage {sub[0]:.0f} rows {sub[1]:.0f} stage {sub[2]:.0f} rows {sub[3]:.0f}+{sub[4]:.0f}]"
+    print(f"{name}\n    tiles {ntiles:6d}  prologue {d[:,0].median():8.0f}  mainloop {d[:,1].median():8.0f} ({d[:,1].median()/iters:6.0f}/iter)"
           f"  epilogue {d[:,2].median():8.0f}  wg total {(s[:,3]-s[:,0]).median():8.0f}  kernel span {span:10.0f} ticks")
 
 
