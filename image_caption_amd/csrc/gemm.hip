@@ -661,9 +661,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
 // tile's HBM/L2 latency is covered by three MFMA phases.  An LDS-DMA writes
 // wave-base + 16*lane, i.e. the LDS image is lane-linear per wave instruction;
 // the bank-conflict swizzle is therefore applied to the per-lane SOURCE address and
-// undone by the same XOR on the fragment read.  Needs K % 32 == 0 (other K: the
-// register-staged kernel above); M/N tails are out-of-range rows whose results are
-// never stored.
+// undone by the same XOR on the fragment read.  Needs K % 32 == 0 unless both operands are
+// reduction-major (other K: the register-staged kernel above); M/N tails are out-of-range
+// rows whose results are never stored.
 constexpr int DBK = 32, DSTAGES = 4, DTILE_BYTES = 8192, DSTAGE_BYTES = 2 * DTILE_BYTES;
 
 // row-major [128 rows][32 k] bf16, 64-B rows; chunk (0..3) XOR 3*((row>>3)&1): conflict-free ds_read_b128
@@ -768,14 +768,22 @@ __global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void ge
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / DBK;
+    // split-K: this block covers k-tiles [kt0, kt0 + nk) and writes its own f32 slab
+    const int nk_total = (p.K + DBK - 1) / DBK;
+    int kt0 = 0, nk = nk_total;
+    if (p.split_k > 1) {
+        const int kper = (nk_total + p.split_k - 1) / p.split_k;
+        kt0 = blockIdx.y * kper;
+        nk = max(0, min(kper, nk_total - kt0));
+        p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
+    }
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
     // a stage index past the last k-tile still issues its (harmless) loads, so that the
     // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
     auto dma_stage = [&](int kt, int slot) {
         char* st = smem + slot * G::STAGE;
-        dma_tile<A_TR, G::NJA, G::NW>(va, offa, kt * DBK, st, wave);
-        dma_tile<B_TR, G::NJB, G::NW>(vb, offb, kt * DBK, st + G::A_BYTES, wave);
+        dma_tile<A_TR, G::NJA, G::NW>(va, offa, (kt0 + kt) * DBK, st, wave);
+        dma_tile<B_TR, G::NJB, G::NW>(vb, offb, (kt0 + kt) * DBK, st + G::A_BYTES, wave);
     };
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) dma_stage(s, s);
@@ -799,8 +807,8 @@ __global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void ge
         // refill of the stage that was read in iteration kt-1: one DMA piece after each row of MFMAs, so that
         // its issue time is covered by matrix work instead of delaying the first MFMA of the step
         char* wst = smem + wslot * G::STAGE;
-        const __amdgpu_buffer_rsrc_t rsa = dma_rsrc<A_TR>(va, (kt + NST - 1) * DBK);
-        const __amdgpu_buffer_rsrc_t rsb = dma_rsrc<B_TR>(vb, (kt + NST - 1) * DBK);
+        const __amdgpu_buffer_rsrc_t rsa = dma_rsrc<A_TR>(va, (kt0 + kt + NST - 1) * DBK);
+        const __amdgpu_buffer_rsrc_t rsb = dma_rsrc<B_TR>(vb, (kt0 + kt + NST - 1) * DBK);
         rslot = rslot + 1 == NST ? 0 : rslot + 1;
         wslot = wslot + 1 == NST ? 0 : wslot + 1;
         constexpr int NP = G::NJA + G::NJB;
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ launch
 unsigned long long* g_stamps = nullptr;
-int g_gemm_mode = 0;     // diagnostic: 1 forces the register-staged kernel
+int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves)
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
@@ -917,50 +925,59 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
     if (in_dtype == CAPDEC_BF16) {
         CAPDEC_CHECK((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm(bf16): lda/ldb must be multiples of 8 (got %ld, %ld)", a.lda, a.ldb);
         CAPDEC_CHECK(aligned16(a.A) && aligned16(a.B), "gemm(bf16): A/B must be 16-byte aligned");
-        using G128 = DmaGeo<2, 4, 4>;
-#define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
+        // Kernel choice.  The LDS-DMA ring needs whole 32-deep k-tiles, except when both operands are
+        // reduction-major (their k-tail lies past the end of the buffer descriptor and reads as zero).
+        // Row-major products always take it, and so does a reduction-major B (dgrad) when the 256-row
+        // geometry applies (row-major A, at least one workgroup per CU).  A reduction-major A (wgrad)
+        // stays on the register-staged kernel, which measured faster on those shapes.
+        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG };
+        const bool any_km = a.a_kmajor || a.b_kmajor;
+        const bool ring_ok = a.K >= DBK && ((a.K % DBK) == 0 || (a.a_kmajor && a.b_kmajor));
+        const int split = a.split_k > 1 ? a.split_k : 1;
+        const long big_tiles = (long)((a.M + 255) / 256) * tn;
+        int kern = KERN_REG;
+        if (ring_ok && !a.a_kmajor) {
+            if (big_tiles * split >= 256 && (!a.b_kmajor || a.K >= 512)) kern = KERN_TALL;
+            else if (!a.b_kmajor) kern = KERN_RING128;
+        }
+        if (g_gemm_mode == 1) kern = KERN_REG;
+        else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
+        else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
+        else if (g_gemm_mode == 4 && ring_ok && !a.a_kmajor) kern = KERN_TALL;
+#define CAPDEC_RING_LAUNCH(AT, BT, WM, TI, NST, NWG)                                                   \
     do {                                                                                               \
+        using G = DmaGeo<WM, TI, NST>;                                                                 \
+        auto kfn = gemm_bf16_dma_kernel<AT, BT, EPI, WM, TI, NST>;                                     \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AT, BT, EPI, 2, 4, 4>,         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, G128::LDS);    \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); \
             attr_set = true;                                                                           \
         }                                                                                              \
-        if (use_dma) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AT, BT, EPI, 2, 4, 4>), grid, block, G128::LDS, st, a); \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);       \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(64 * G::NW), G::LDS, st, a);       \
     } while (0)
-        // the DMA ring wins on row-major x row-major operands; reduction-major operands (transposing
-        // LDS reads, two per fragment) and split-K stay on the register-staged kernel
-        const bool use_dma = (a.K % DBK) == 0 && a.K >= DBK && !a.a_kmajor && !a.b_kmajor && a.split_k <= 1 && g_gemm_mode != 1;
-        const long big_tiles = (long)((a.M + 255) / 256) * tn;
-        // 256-row tiles: 4 waves of 128x64, two workgroups per CU, whenever they still give every CU work
-        const bool use_tall = use_dma && ((big_tiles >= 256 && g_gemm_mode == 0) || g_gemm_mode == 4);
-        const bool use_big = use_dma && g_gemm_mode == 3;       // diagnostic: 8 waves, one workgroup per CU
-        if (use_tall) {
-            using G = DmaGeo<2, 8, 3>;
-            static bool tall_attr = false;
-            if (!tall_attr) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 2, 8, 3>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-                tall_attr = true;
-            }
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 2, 8, 3>), dim3((unsigned)big_tiles), dim3(256), G::LDS, st, a);
-        } else if (use_big) {
-            using G = DmaGeo<4, 4, 4>;
-            static bool big_attr = false;
-            if (!big_attr) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false, EPI, 4, 4, 4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-                big_attr = true;
-            }
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, EPI, 4, 4, 4>), dim3((unsigned)big_tiles), dim3(512), G::LDS, st, a);
-        } else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
+#define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
+    do {                                                                                               \
+        if (kern == KERN_RING128) CAPDEC_RING_LAUNCH(AT, BT, 2, 4, 4, nwg);                            \
+        else {                                                                                         \
+            static bool attr_set = false;                                                              \
+            if (!attr_set) {                                                                           \
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);      \
+                attr_set = true;                                                                       \
+            }                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);        \
+        }                                                                                              \
+    } while (0)
+        if (kern == KERN_TALL) {
+            if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 8, 3, big_tiles);
+            else CAPDEC_RING_LAUNCH(false, false, 2, 8, 3, big_tiles);
+        } else if (kern == KERN_BIG) CAPDEC_RING_LAUNCH(false, false, 4, 4, 4, big_tiles);
+        else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
         else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
         else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
         else CAPDEC_GEMM_CASE(true, true);
 #undef CAPDEC_GEMM_CASE
+#undef CAPDEC_RING_LAUNCH
     } else {
         static bool attr_set = false;
         if (!attr_set) {

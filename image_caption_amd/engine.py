@@ -89,8 +89,10 @@ class ParamStore:
         self.layout: List = []            # (key, shape, offset)
         off = 0
         # head first: its gradient is produced first in backward, so its all-reduce can start first
-        for key, shape in ((HEAD_W, (V, d)), (HEAD_B, (V,))):
-            n = math.prod(shape)
+        # the vocabulary matrix is followed by zero rows up to a multiple of 128 rows (they stay zero: their
+        # gradient is never written), so that products over the vocabulary can run whole 128-row tiles
+        self.head_pad_rows = (V + 127) // 128 * 128 - V
+        for key, shape, n in ((HEAD_W, (V, d), (V + self.head_pad_rows) * d), (HEAD_B, (V,), V)):
             self.layout.append((key, shape, off))
             off += (n + 63) // 64 * 64
         for i in reversed(range(geo.n_blocks)):
@@ -157,10 +159,11 @@ class _Weights:
     """Per-call view of the tensors the kernels read: matrices in compute dtype,
     biases / LayerNorm affine in f32."""
 
-    def __init__(self, blocks, head_w, head_b):
+    def __init__(self, blocks, head_w, head_b, head_pad_rows: int = 0):
         self.blocks = blocks
         self.head_w = head_w
         self.head_b = head_b
+        self.head_pad_rows = head_pad_rows      # zero rows that physically follow head_w's last row
 
 
 def weights_from_store(store: ParamStore) -> _Weights:
@@ -172,7 +175,7 @@ def weights_from_store(store: ParamStore) -> _Weights:
             key = block_key(i, name, geo.n_blocks)
             b[name] = store.compute(key) if name in MATRIX_KEYS else store.param(key)
         blocks.append(b)
-    return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B))
+    return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows)
 
 
 class DecoderEngine:
@@ -356,13 +359,17 @@ class DecoderEngine:
             dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)
             with self._span("logits_ce_bwd_slab"):
                 ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
-            with self._span("head_dgrad_slab"):
-                ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=nv, b_kmajor=True, accumulate=not first, workspace=hws)
+            # the weight gradient first: nothing downstream waits for it but its all-reduce
             with self._span("head_wgrad_slab"):
                 ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
-            first = False
             if on_grad_ready is not None:
                 on_grad_ready(HEAD_W, v0, nv)
+            # the slab's padding columns of dl are zero, and so are the rows that follow the vocabulary matrix
+            # in a flat parameter store: the reduction may then run over whole tiles
+            kk = ld if v0 + ld <= V + W.head_pad_rows else nv
+            with self._span("head_dgrad_slab"):
+                ops.gemm(dls, W.head_w[v0:], dH, M=Mh, N=d, K=kk, b_kmajor=True, accumulate=not first, workspace=hws)
+            first = False
         if on_grad_ready is not None:
             on_grad_ready(HEAD_B, 0, V)
         # ---- blocks backward

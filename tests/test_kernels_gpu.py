@@ -77,6 +77,24 @@ def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
     close(out2, ref + res, 1.5e-2, f"mode {mode} + residual")
 
 
+@pytest.mark.parametrize("mode", [1, 2, 4])
+@pytest.mark.parametrize("akm,bkm", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(264, 136, 96), (520, 72, 2080), (136, 264, 100)])
+def test_gemm_reduction_major_every_geometry(gemm_mode, mode, akm, bkm, M, N, K):
+    # K = 100 is not a whole number of 32-deep tiles: only the all-reduction-major case may take the ring
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=35), rnd(N, K, dtype=torch.bfloat16, scale=0.1, seed=36)
+    if K % 8 and not (akm and bkm):
+        pytest.skip("row-major bf16 operands need a leading dimension that is a multiple of 8")
+    Aop = A.t().contiguous() if akm else A
+    Bop = B.t().contiguous() if bkm else B
+    ref = A.float() @ B.float().t()
+    gemm_mode(mode)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Aop, Bop, out, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm)
+    gemm_mode(0)
+    close(out, ref, 1.5e-2, f"mode {mode}")
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_logits_ce_every_geometry(gemm_mode, mode):
     B_, L, V, d = 5, 8, 1111, 64                       # 40 rows: ragged in M; 1111 columns: ragged in N
@@ -109,7 +127,9 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
 
 
 @pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
-def test_gemm_split_k(M, N, K, out):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gemm_split_k(gemm_mode, mode, M, N, K, out):
+    gemm_mode(mode)
     # weight-gradient shape: few output tiles, deep K; both operands reduction-major
     A = rnd(K, M, dtype=torch.bfloat16, seed=70)
     B = rnd(K, N, dtype=torch.bfloat16, scale=0.1, seed=71)

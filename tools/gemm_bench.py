@@ -102,6 +102,30 @@ def main():
     t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
     print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
     print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU)")
+    Vp = (V + 127) // 128 * 128
+    dlw = torch.zeros(Mt, Vp, device=DEV, dtype=BF)
+    dlw[:, :V] = (torch.randn(Mt, V, device=DEV, generator=g) * 1e-3).to(BF)
+    wvp = torch.zeros(Vp, d, device=DEV, dtype=BF)
+    wvp[:V] = wv
+    dWw = torch.empty(V, d, device=DEV)
+    hws = torch.empty(8 * Mt * d * 4, dtype=torch.uint8, device=DEV)
+    kcases = {
+        "head dgrad slab 8192x768x8192 (B kmajor)": (2.0 * Mt * slab * d, lambda: ops.gemm(dl, wv[:slab], dH, b_kmajor=True)),
+        "head dgrad 8192x768x50304 (B kmajor, split-K)": (2.0 * Mt * Vp * d, lambda: ops.gemm(dlw, wvp, dH, M=Mt, N=d, K=Vp, b_kmajor=True, workspace=hws)),
+        "head wgrad slab 8192x768x8192 (A,B kmajor)": (2.0 * Mt * slab * d, lambda: ops.gemm(dl, x_t, dW, a_kmajor=True, b_kmajor=True)),
+        "head wgrad 50260x768x8192 (A,B kmajor)": (2.0 * Mt * V * d, lambda: ops.gemm(dlw, x_t, dWw, M=V, N=d, K=Mt, a_kmajor=True, b_kmajor=True)),
+        "dgrad KV 58624x768x1536 (B kmajor)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, w_kv, dh1, b_kmajor=True)),
+        "wgrad KV 1536x768x58624 (A,B kmajor, split-K)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, x_all, gkv, a_kmajor=True, b_kmajor=True, workspace=skws)),
+    }
+    print("reduction-major operands: register | ring128 | ring256 (4 waves) | default")
+    for name, (fl, fn) in kcases.items():
+        res = {1: [], 2: [], 4: [], 0: []}
+        for _ in range(5):
+            for mode in (1, 2, 4, 0):
+                lib.capdecdbg_gemm_mode(mode)
+                res[mode].append(fl / timeit(fn, 5) / 1e9)
+        lib.capdecdbg_gemm_mode(0)
+        print(f"{name:48s} " + " | ".join(f"{sorted(res[m])[2]:7.1f}" for m in (1, 2, 4, 0)))
     for name, (fl, fn) in cases.items():
         res = {1: [], 2: [], 3: [], 4: []}
         for _ in range(5):
