@@ -86,11 +86,13 @@ SIGNATURES = {
     "capdec_last_error": (C.c_char_p, []),
     "capdec_dropout_mask": (c_int, [Dropout, c_long, c_void_p, c_void_p]),
     "capdec_concat_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
-                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                     c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_ln_bwd_workspace": (c_long, [c_long, c_int]),
     "capdec_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "capdec_concat_ln_bwd_affine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "capdec_gemm_bias_act": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "capdec_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "capdec_attn_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
@@ -106,8 +108,9 @@ SIGNATURES = {
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
-    "capdec_dropout_bwd_cast": (c_int, [c_void_p, c_long, c_int, Dropout, c_void_p, c_int, c_void_p, c_void_p]),
-    "capdec_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
+    "capdec_colsum_workspace": (c_long, [c_long, c_int]),
+    "capdec_dropout_bwd_cast": (c_int, [c_void_p, c_long, c_int, Dropout, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
+    "capdec_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_embed_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),

@@ -1151,10 +1151,17 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     const bool plain = !a.bias && a.col_scale_n == 0 && a.act == CAPDEC_ACT_NONE && !a.drop_thr && !a.residual &&
                        a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache;
     if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 512 && nkt >= 32) {
-        // aim at >= 3 full rounds of the 512 resident workgroups, so that the last, partly filled round costs little
-        long split = (1536 + tiles - 1) / tiles;
-        if (split > 8) split = 8;
-        if (split > nkt / 8) split = nkt / 8;
+        // the split that best fills whole rounds of the 512 resident workgroups (two per CU), counted in the
+        // tiles of the kernel that will run; the smallest such split, since every slab is written and re-read
+        const bool tall_possible = !a.a_kmajor && a.K >= 512 && (a.K % 32) == 0;
+        const long unit = tall_possible ? (long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) : tiles;
+        long split = 1;
+        double best = 0.0;
+        for (long sp = 1; sp <= 8 && sp <= nkt / 8; ++sp) {
+            const long n = unit * sp;
+            const double eff = (double)n / (double)((n + 511) / 512 * 512);
+            if (eff > best + 0.03) { best = eff; split = sp; }
+        }
         const long slab = (long)a.M * a.N;
         if (split > 1 && d->workspace_bytes >= split * slab * 4) {
             GemmArgs b = a;

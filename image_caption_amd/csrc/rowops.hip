@@ -46,10 +46,11 @@ template <typename TIN, typename TOUT, bool CONCAT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* sos, const TIN* cap, const float* xin,
                                                       const float* pos, const float* gamma, const float* beta, float eps,
                                                       long M, int B, int P, int L, int d,
-                                                      float* xout, TOUT* y, float* mean, float* rstd) {
+                                                      float* xout, long x_row0, TOUT* y, float* mean, float* rstd) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
+    if (r < x_row0) xout = nullptr;          // the joined row itself is only kept from x_row0 on
     f32x4 v[LN_VEC];
     float sum = 0.f;
     long s = 0;
@@ -102,8 +103,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* 
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename TDY>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const float* gamma,
+// x comes either from a [M,d] f32 buffer or (CONCAT) straight from the three tensors the forward
+// joined, so the joined rows need not be kept.  dx_out == NULL: only the affine gradients are wanted
+// (the first block's input is data), which drops the two row reductions and the row store.
+template <typename TDY, typename TIN, bool CONCAT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const TIN* img, const TIN* sos, const TIN* cap,
+                                                      const float* pos, int B, int P, int L, const float* gamma,
                                                       const float* mean, const float* rstd, long M, int d,
                                                       const float* dx_in, float* dx_out, float* partial) {
     __shared__ __attribute__((aligned(16))) float red[4 * 2 * 64 * 4];   // [wave][dgamma|dbeta][lane][4], one 1024-column slab per pass
@@ -114,6 +119,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
     const long nwaves = (long)gridDim.x * 4;
     for (long r = (long)blockIdx.x * 4 + wave; r < M; r += nwaves) {
         const float mu = mean[r], rs = rstd[r];
+        long sq = 0;
+        const TIN* src = nullptr;
+        if constexpr (CONCAT) {
+            sq = r / B;
+            const long b = r - sq * B;
+            src = sq < P ? img + (b * P + sq) * d : (sq == P ? sos + b * d : cap + (b * L + (sq - P - 1)) * d);
+        }
         f32x4 g[LN_VEC], xh[LN_VEC];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -122,7 +134,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
             g[i] = f32x4{0, 0, 0, 0}; xh[i] = f32x4{0, 0, 0, 0};
             if (c < d) {
                 const f32x4 dyv = load4<TDY>(dy + r * d + c);
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * d + c);
+                f32x4 xv;
+                if constexpr (CONCAT) {
+                    xv = load4<TIN>(src + c);
+                    if (pos) xv += *reinterpret_cast<const f32x4*>(pos + sq * d + c);
+                } else {
+                    xv = *reinterpret_cast<const f32x4*>(x + r * d + c);
+                }
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -135,17 +153,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
                 }
             }
         }
-        c1 = wave_sum(c1) / d;
-        c2 = wave_sum(c2) / d;
+        if (dx_out) {
+            c1 = wave_sum(c1) / d;
+            c2 = wave_sum(c2) / d;
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) {
-            const int c = lane * 4 + i * 256;
-            if (c < d) {
-                f32x4 o;
+            for (int i = 0; i < LN_VEC; ++i) {
+                const int c = lane * 4 + i * 256;
+                if (c < d) {
+                    f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-                if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + r * d + c);
-                *reinterpret_cast<f32x4*>(dx_out + r * d + c) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+                    if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + r * d + c);
+                    *reinterpret_cast<f32x4*>(dx_out + r * d + c) = o;
+                }
             }
         }
     }
@@ -206,46 +226,75 @@ __global__ void dropout_mask_kernel(uint32_t thr, uint32_t k0, uint32_t k1, long
         out[i] = (!thr || dropout_keep(k0, k1, (uint32_t)i, thr)) ? 1.f : 0.f;
 }
 
-// g = dx * keep/(1-p), column sums into colsum; thread owns 4 columns, block owns ROWS rows
-constexpr int CS_ROWS = 64;
-template <typename TG>
-__global__ __launch_bounds__(256) void dropout_bwd_cast_kernel(const float* dx, long M, int N, uint32_t thr, uint32_t k0, uint32_t k1,
-                                                                float scale, TG* g, float* colsum) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (n >= N) return;
-    const long r0 = (long)blockIdx.y * CS_ROWS;
-    const long r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+// Column sums in two deterministic stages.  Stage 1: a block owns a stripe of rows x 256 columns; a
+// thread owns 4 columns and every 4th row of the stripe (4 loads in flight), the 4 row lanes are folded
+// through LDS, and the stripe's sums go to partial[stripe][N].  With DROP the same pass also writes
+// g = dx * keep/(1-p) in g's type (backward of `x + dropout(y)` w.r.t. y).  Stage 2 folds the stripes
+// in a fixed order.
+template <typename TI, typename TG, bool DROP>
+__global__ __launch_bounds__(256) void colsum_stripe_kernel(const TI* x, long M, int N, long ldx, int rows_per_stripe,
+                                                             uint32_t thr, uint32_t k0, uint32_t k1, float scale,
+                                                             TG* g, float* partial) {
+    __shared__ __attribute__((aligned(16))) float red[4][64][4];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + cg * 4;
+    const long r0 = (long)blockIdx.y * rows_per_stripe;
+    const long r1 = r0 + rows_per_stripe < M ? r0 + rows_per_stripe : M;
     f32x4 acc = f32x4{0, 0, 0, 0};
-    const bool full = n + 3 < N && (N & 3) == 0;
-    for (long r = r0; r < r1; ++r) {
-        f32x4 v = f32x4{0, 0, 0, 0};
-        if (full) v = *reinterpret_cast<const f32x4*>(dx + r * N + n);
-        else for (int e = 0; e < 4 && n + e < N; ++e) v[e] = dx[r * N + n + e];
-        if (thr) {
+    if (n < N) {
+        const bool full = n + 3 < N && (ldx & 3) == 0 && (!DROP || (N & 3) == 0);
+        auto one_row = [&](long r) {
+            f32x4 v = f32x4{0, 0, 0, 0};
+            if (full) v = load4<TI>(x + r * ldx + n);
+            else for (int e = 0; e < 4 && n + e < N; ++e) v[e] = to_f32<TI>(x[r * ldx + n + e]);
+            if constexpr (DROP) {
+                if (thr) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dropout_keep(k0, k1, (uint32_t)(r * N + n + e), thr) ? v[e] * scale : 0.f;
-        }
-        if (full) store4<TG>(g + r * N + n, v);
-        else for (int e = 0; e < 4 && n + e < N; ++e) g[r * N + n + e] = from_f32<TG>(v[e]);
-        acc += v;
+                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(k0, k1, (uint32_t)(r * N + n + e), thr) ? v[e] * scale : 0.f;
+                }
+                if (full) store4<TG>(g + r * N + n, v);
+                else for (int e = 0; e < 4 && n + e < N; ++e) g[r * N + n + e] = from_f32<TG>(v[e]);
+            }
+            acc += v;
+        };
+        long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) { one_row(r); one_row(r + 4); one_row(r + 8); one_row(r + 12); }
+        for (; r < r1; r += 4) one_row(r);
     }
-    if (colsum)
-        for (int e = 0; e < 4 && n + e < N; ++e) atomicAdd(colsum + n + e, acc[e]);
+    if (!partial) return;
+    *reinterpret_cast<f32x4*>(&red[rl][cg][0]) = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        f32x4 t = acc;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(&red[w][cg][0]);
+        for (int e = 0; e < 4 && n + e < N; ++e) partial[(long)blockIdx.y * N + n + e] = t[e];
+    }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int N, long ldx, float* colsum) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (n >= N) return;
-    const long r0 = (long)blockIdx.y * CS_ROWS;
-    const long r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
-    f32x4 acc = f32x4{0, 0, 0, 0};
-    const bool full = n + 3 < N && (ldx & 3) == 0;
-    for (long r = r0; r < r1; ++r) {
-        if (full) acc += load4<T>(x + r * ldx + n);
-        else for (int e = 0; e < 4 && n + e < N; ++e) acc[e] += to_f32<T>(x[r * ldx + n + e]);
+// out[n] = sum over stripes of partial[stripe][n]: 64 columns per block, 16 row groups, fixed-order fold
+__global__ __launch_bounds__(1024) void stripe_fold_kernel(const float* partial, int nstripes, int N, float* out) {
+    __shared__ float sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f;
+    if (c < N)
+        for (int k = ty; k < nstripes; k += 16) a += partial[(long)k * N + c];
+    sh[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r += sh[j][tx];
+        out[c] = r;
     }
-    for (int e = 0; e < 4 && n + e < N; ++e) atomicAdd(colsum + n + e, acc[e]);
+}
+
+// rows per stripe: about 512 stripes, at least 16 rows each, a multiple of the 4 row lanes
+int colsum_stripe_rows(long M) {
+    long r = (M + 511) / 512;
+    if (r < 16) r = 16;
+    return (int)((r + 3) / 4 * 4);
 }
 
 __global__ void embed_rows_kernel(const float* table, const int64_t* ids, long n, int d, const float* pos_row, float* out) {
@@ -325,27 +374,28 @@ extern "C" int capdec_dropout_mask(capdec_dropout d, long n, float* out, void* s
 template <typename TIN, typename TOUT, bool CONCAT>
 static void launch_ln_fwd(const void* img, const void* sos, const void* cap, const float* xin, const float* pos,
                           const float* gamma, const float* beta, float eps, long M, int B, int P, int L, int d,
-                          float* xout, void* y, float* mean, float* rstd, hipStream_t st) {
+                          float* xout, long x_row0, void* y, float* mean, float* rstd, hipStream_t st) {
     hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
                        (const TIN*)img, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
-                       xout, (TOUT*)y, mean, rstd);
+                       xout, x_row0, (TOUT*)y, mean, rstd);
 }
 
 extern "C" int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int in_dtype,
                                     const float* pos, const float* gamma, const float* beta, float eps,
                                     int B, int P, int L, int d,
-                                    float* x, void* y, int y_dtype, float* mean, float* rstd, void* stream) {
+                                    float* x, long x_row0, void* y, int y_dtype, float* mean, float* rstd, void* stream) {
     CAPDEC_CHECK(img && sos && cap, "concat_ln_fwd: null input");
+    CAPDEC_CHECK(x_row0 >= 0, "concat_ln_fwd: negative x_row0");
     CAPDEC_CHECK(B > 0 && P >= 0 && L >= 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "concat_ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
     CAPDEC_CHECK(x || y, "concat_ln_fwd: nothing to write");
     CAPDEC_CHECK(!y || (gamma && beta), "concat_ln_fwd: LayerNorm output needs gamma/beta");
     const long M = (long)(P + 1 + L) * B;
     hipStream_t st = (hipStream_t)stream;
     const bool ib = in_dtype == CAPDEC_BF16, ob = y_dtype == CAPDEC_BF16;
-    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
-    else if (ib) launch_ln_fwd<bf16_t, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
-    else if (ob) launch_ln_fwd<float, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
-    else launch_ln_fwd<float, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, y, mean, rstd, st);
+    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else if (ib) launch_ln_fwd<bf16_t, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else if (ob) launch_ln_fwd<float, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -356,8 +406,8 @@ extern "C" int capdec_ln_fwd(const float* x, const float* gamma, const float* be
     CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
     if (M <= 0) return CAPDEC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (y_dtype == CAPDEC_BF16) launch_ln_fwd<float, bf16_t, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, y, mean, rstd, st);
-    else launch_ln_fwd<float, float, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, y, mean, rstd, st);
+    if (y_dtype == CAPDEC_BF16) launch_ln_fwd<float, bf16_t, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -368,15 +418,42 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
                              const float* mean, const float* rstd, long M, int d,
                              const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
                              void* partial, void* stream) {
-    CAPDEC_CHECK(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && partial, "ln_bwd: null pointer");
+    CAPDEC_CHECK(dy && x && gamma && mean && rstd && dgamma && dbeta && partial, "ln_bwd: null pointer");
     CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_bwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
     if (M <= 0) return CAPDEC_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nb = ln_bwd_blocks(M);
+    const float* nf = nullptr;
     if (dy_dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float, false>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, nf, nf, nf, nf, 1, 0, 0,
+                           gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, x, gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float, false>), dim3(nb), dim3(256), 0, st, (const float*)dy, x, nf, nf, nf, nf, 1, 0, 0,
+                           gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const void* img, const void* sos, const void* cap, int in_dtype,
+                                           const float* pos, const float* gamma, const float* mean, const float* rstd,
+                                           int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, void* stream) {
+    CAPDEC_CHECK(dy && img && sos && cap && gamma && mean && rstd && dgamma && dbeta && partial, "concat_ln_bwd_affine: null pointer");
+    CAPDEC_CHECK(B > 0 && P >= 0 && L >= 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "concat_ln_bwd_affine: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    const long M = (long)(P + 1 + L) * B;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_bwd_blocks(M);
+    const float* nf = nullptr;
+    float* nd = nullptr;
+#define CAPDEC_LNB(TDY, TIN)                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TIN, true>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, nf, (const TIN*)img,   \
+                       (const TIN*)sos, (const TIN*)cap, pos, B, P, L, gamma, mean, rstd, M, d, nf, nd, (float*)partial)
+    const bool db = dy_dtype == CAPDEC_BF16, ib = in_dtype == CAPDEC_BF16;
+    if (db && ib) CAPDEC_LNB(bf16_t, bf16_t);
+    else if (db) CAPDEC_LNB(bf16_t, float);
+    else if (ib) CAPDEC_LNB(float, bf16_t);
+    else CAPDEC_LNB(float, float);
+#undef CAPDEC_LNB
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -395,28 +472,58 @@ extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dt
     return CAPDEC_OK;
 }
 
+extern "C" long capdec_colsum_workspace(long M, int N) {
+    const int rows = colsum_stripe_rows(M);
+    return ((M + rows - 1) / rows) * (long)N * 4 + 16;
+}
+
 extern "C" int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
-                                       void* g, int g_dtype, float* colsum, void* stream) {
+                                       void* g, int g_dtype, float* colsum,
+                                       void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(dx && g && M >= 0 && N > 0, "dropout_bwd_cast: bad arguments");
     CAPDEC_CHECK(M * N < (1L << 32) || d.p <= 0.f, "dropout_bwd_cast: dropout index space exceeds 2^32 elements");
-    if (M == 0) return CAPDEC_OK;
+    if (colsum && (!workspace || workspace_bytes < capdec_colsum_workspace(M, N))) {
+        capdec_set_error("dropout_bwd_cast: workspace too small (%ld < %ld)", workspace_bytes, capdec_colsum_workspace(M, N));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        if (colsum) (void)hipMemsetAsync(colsum, 0, (size_t)N * 4, st);
+        return CAPDEC_OK;
+    }
     const uint32_t thr = d.p > 0.f ? dropout_threshold(d.p) : 0u;
     const float scale = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
-    dim3 grid((N + 1023) / 1024, (unsigned)((M + CS_ROWS - 1) / CS_ROWS)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (g_dtype == CAPDEC_BF16) hipLaunchKernelGGL(dropout_bwd_cast_kernel<bf16_t>, grid, block, 0, st, dx, M, N, thr, d.key0, d.key1, scale, (bf16_t*)g, colsum);
-    else hipLaunchKernelGGL(dropout_bwd_cast_kernel<float>, grid, block, 0, st, dx, M, N, thr, d.key0, d.key1, scale, (float*)g, colsum);
+    const int rows = colsum_stripe_rows(M);
+    const int nstripes = (int)((M + rows - 1) / rows);
+    dim3 grid((N + 255) / 256, (unsigned)nstripes), block(256);
+    float* part = colsum ? (float*)workspace : nullptr;
+    if (g_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, bf16_t, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (bf16_t*)g, part);
+    else
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (float*)g, part);
+    if (colsum) hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)part, nstripes, N, colsum);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
 
-extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream) {
+extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum,
+                             void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(x && colsum && M >= 0 && N > 0 && ldx >= N, "colsum: bad arguments");
-    if (M == 0) return CAPDEC_OK;
-    dim3 grid((N + 1023) / 1024, (unsigned)((M + CS_ROWS - 1) / CS_ROWS)), block(256);
+    if (!workspace || workspace_bytes < capdec_colsum_workspace(M, N)) {
+        capdec_set_error("colsum: workspace too small (%ld < %ld)", workspace_bytes, capdec_colsum_workspace(M, N));
+        return CAPDEC_ERR_WORKSPACE;
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CAPDEC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, M, N, ldx, colsum);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, M, N, ldx, colsum);
+    if (M == 0) { (void)hipMemsetAsync(colsum, 0, (size_t)N * 4, st); return CAPDEC_OK; }
+    const int rows = colsum_stripe_rows(M);
+    const int nstripes = (int)((M + rows - 1) / rows);
+    dim3 grid((N + 255) / 256, (unsigned)nstripes), block(256);
+    float* nog = nullptr;
+    if (dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL((colsum_stripe_kernel<bf16_t, float, false>), grid, block, 0, st, (const bf16_t*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace);
+    else
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, false>), grid, block, 0, st, (const float*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace);
+    hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)workspace, nstripes, N, colsum);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -266,7 +266,8 @@ class DecoderEngine:
         return x_out
 
     # ------------------------------------------------------------------ forward to the scored rows
-    def forward_hidden(self, W: _Weights, source, *, L_scored: Optional[int], train: bool, step: int = 0, pos=None):
+    def forward_hidden(self, W: _Weights, source, *, L_scored: Optional[int], train: bool, step: int = 0, pos=None,
+                       keep_joined: bool = True):
         """source = ("concat", img, sos, cap) or ("tensor", tgt[S,B,d]).  Returns
         (x [rows, d] f32 of the last block, first row index r0, B, S)."""
         geo = self.geo
@@ -297,15 +298,22 @@ class DecoderEngine:
                 h1 = self.buf("h1.0", (M, d), self.cdt, dev)
                 mean1 = self.buf("mean1.0", (M,), torch.float32, dev)
                 rstd1 = self.buf("rstd1.0", (M,), torch.float32, dev)
+                concat_src = None
                 if source[0] == "concat":
+                    # the joined rows are only needed as the residual of the rows block 0 carries on (and by a
+                    # LayerNorm backward that must return an input gradient): otherwise they are not kept, and
+                    # the backward reads img / sos / cap again
                     x0 = self.buf("x0", (M, d), torch.float32, dev)
-                    ops.concat_ln_fwd(img, sos, cap, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0, y_out=h1, mean=mean1, rstd=rstd1)
+                    ops.concat_ln_fwd(img, sos, cap, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0,
+                                      x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
+                    concat_src = (img, sos, cap, pos)
                 else:
                     x0 = tgt.reshape(M, d)
                     if x0.dtype != torch.float32 or not x0.is_contiguous():
                         x0 = x0.float().contiguous()
                     ops.ln_fwd(x0, w0["norm1.weight"], w0["norm1.bias"], h1, mean1, rstd1)
                 x = self._block_fwd(0, W, x0, B, S, q0, train, step, dev, h1_ready=(h1, mean1, rstd1))
+                self.saved[0]["concat_src"] = concat_src
             else:
                 x = self._block_fwd(i, W, x, B, S, q0, train, step, dev)
         self._shape = (B, S, last_q0)
@@ -322,7 +330,8 @@ class DecoderEngine:
         d, V = geo.d_model, geo.vocab_size
         _lib.require_cuda(labels)
         Bl, L = labels.shape
-        x, r0, B, S = self.forward_hidden(W, source, L_scored=L, train=train, step=step, pos=pos)
+        x, r0, B, S = self.forward_hidden(W, source, L_scored=L, train=train, step=step, pos=pos,
+                                          keep_joined=need_input_grad or not want_grads)
         assert Bl == B, "labels batch does not match inputs"
         dev = labels.device
         Mh = L * B
@@ -351,7 +360,7 @@ class DecoderEngine:
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
         bws = self.buf("ce_bwd_ws", (ops.logits_ce_bwd_workspace(Mh, slab),), torch.uint8, dev)
-        hws = self.buf("head_splitk_ws", (4 * Mh * d * 4,), torch.uint8, dev)
+        hws = self.buf("head_splitk_ws", (8 * Mh * d * 4,), torch.uint8, dev)
         first = True
         for v0 in range(0, V, slab):
             nv = min(slab, V - v0)
@@ -403,11 +412,11 @@ class DecoderEngine:
         k_attn, k_r1, k_h, k_r2 = sv["keys"]
         G = lambda name: grads[block_key(i, name, nbk)]           # noqa: E731
         skws = self.buf("splitk_ws", (8 * max(3 * d * d, d * ff) * 4,), torch.uint8, dev)
-        for name in ("self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias", "linear2.bias"):
-            G(name).zero_()
+        csws = self.buf("colsum_ws", (max(ops.colsum_workspace(M, 3 * d), ops.colsum_workspace(Mt, 3 * d)),), torch.uint8, dev)
+        G("linear1.bias").zero_()            # summed by atomics in a GEMM epilogue; the other bias gradients are overwritten
         # ---- MLP
         g2 = self.buf("g_res", (Mt, d), cdt, dev)
-        ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"))
+        ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
         ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         if self.opt.activation == "relu":
@@ -424,7 +433,7 @@ class DecoderEngine:
         ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
         # ---- attention
         g1 = g2
-        ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"))
+        ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"), csws)
         ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
         dattn = self.buf("dattn", (M, d), cdt, dev)
         ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
@@ -435,15 +444,33 @@ class DecoderEngine:
         gin_w, gin_b = G("self_attn.in_proj_weight"), G("self_attn.in_proj_bias")
         h1 = sv["h1"]
         if q_start == 0:
-            ops.colsum(dqkv, gin_b)
+            ops.colsum(dqkv, gin_b, csws)
             ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
         else:
-            ops.colsum(dqkv[r0:, :d], gin_b[:d])
-            ops.colsum(dqkv[:, d:], gin_b[d:])
+            ops.colsum(dqkv[r0:, :d], gin_b[:d], csws)
+            ops.colsum(dqkv[:, d:], gin_b[d:], csws)
             ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
             ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
+        if not need_dx_in:
+            # no gradient flows below this block: dh1 only feeds norm1's affine gradients, so it is kept in
+            # the compute dtype, rows below / from r0 come from two products over disjoint rows, and the
+            # LayerNorm backward skips dx (reading the joined rows from their sources when they were not kept)
+            dh1 = self.buf("dh1c", (M, d), cdt, dev)
+            if q_start == 0:
+                ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
+            else:
+                ops.gemm(dqkv[:r0, d:], in_w[d:], dh1[:r0], M=r0, N=d, K=2 * d, b_kmajor=True)
+                ops.gemm(dqkv[r0:], in_w, dh1[r0:], M=Mt, N=d, K=3 * d, b_kmajor=True)
+            src = sv.get("concat_src")
+            if src is not None:
+                ops.concat_ln_bwd_affine(dh1, src[0], src[1], src[2], w["norm1.weight"], sv["mean1"], sv["rstd1"],
+                                         G("norm1.weight"), G("norm1.bias"), lnws, pos=src[3])
+            else:
+                ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], None, None,
+                           G("norm1.weight"), G("norm1.bias"), lnws)
+            return None
         dh1 = self.buf("dh1", (M, d), torch.float32, dev)
         if q_start == 0:
             ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
@@ -483,7 +510,6 @@ class DecoderEngine:
         dl = self.buf("dl_all", (M, Vp), cdt, dev, zero=True)
         dl[:, :V].copy_(dlogits.reshape(M, V))
         h = self._all_in
-        grads[HEAD_B].zero_()
         ops.colsum(dl[:, :V], grads[HEAD_B])
         ops.gemm(dl, h, grads[HEAD_W], M=V, N=d, K=M, a_kmajor=True, b_kmajor=True)
         dx = self.buf("dx_all", (M, d), torch.float32, dev)

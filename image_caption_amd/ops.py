@@ -37,7 +37,7 @@ def dropout_mask(d: Dropout, n: int, device) -> torch.Tensor:
     return out
 
 
-def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None, y_out=None, mean=None, rstd=None):
+def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None, x_row0=0, y_out=None, mean=None, rstd=None):
     require_cuda(img, sos, cap, pos, gamma, beta, x_out, y_out, mean, rstd)
     B, P, d = img.shape
     L = cap.shape[1]
@@ -45,7 +45,7 @@ def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None,
     assert img.is_contiguous() and sos.is_contiguous() and cap.is_contiguous()
     assert img.dtype == sos.dtype == cap.dtype
     check(_lib.load().capdec_concat_ln_fwd(ptr(img), ptr(sos), ptr(cap), dtype_code(img), ptr(pos), ptr(gamma), ptr(beta),
-                                           eps, B, P, L, d, ptr(x_out), ptr(y_out),
+                                           eps, B, P, L, d, ptr(x_out), x_row0, ptr(y_out),
                                            dtype_code(y_out) if y_out is not None else F32, ptr(mean), ptr(rstd), _st()),
           "capdec_concat_ln_fwd")
 
@@ -63,11 +63,23 @@ def ln_bwd_workspace(M, d) -> int:
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx_out, dgamma, dbeta, partial):
+    """dx_out None: only the affine gradients."""
     require_cuda(dy, x, gamma, mean, rstd, dx_out, dgamma, dbeta, partial)
     M, d = x.shape
-    assert dy.is_contiguous() and x.is_contiguous() and dx_out.is_contiguous()
+    assert dy.is_contiguous() and x.is_contiguous() and (dx_out is None or dx_out.is_contiguous())
     check(_lib.load().capdec_ln_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), M, d,
                                     ptr(dx_in), ptr(dx_out), ptr(dgamma), ptr(dbeta), ptr(partial), _st()), "capdec_ln_bwd")
+
+
+def concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dgamma, dbeta, partial, pos=None):
+    require_cuda(dy, img, sos, cap, pos, gamma, mean, rstd, dgamma, dbeta, partial)
+    B, P, d = img.shape
+    L = cap.shape[1]
+    assert dy.is_contiguous() and dy.shape == ((P + 1 + L) * B, d)
+    assert img.is_contiguous() and sos.is_contiguous() and cap.is_contiguous() and img.dtype == sos.dtype == cap.dtype
+    check(_lib.load().capdec_concat_ln_bwd_affine(ptr(dy), dtype_code(dy), ptr(img), ptr(sos), ptr(cap), dtype_code(img), ptr(pos),
+                                                  ptr(gamma), ptr(mean), ptr(rstd), B, P, L, d, ptr(dgamma), ptr(dbeta),
+                                                  ptr(partial), _st()), "capdec_concat_ln_bwd_affine")
 
 
 def _ld(t: torch.Tensor) -> int:
@@ -213,17 +225,34 @@ def cast(src, dst):
     return dst
 
 
-def dropout_bwd_cast(dx, drop: Dropout, g, colsum=None):
-    require_cuda(dx, g, colsum)
+def colsum_workspace(M, N) -> int:
+    return _lib.load().capdec_colsum_workspace(M, N)
+
+
+def _colsum_ws(workspace, M, N, device):
+    if workspace is None:
+        workspace = torch.empty(colsum_workspace(M, N), dtype=torch.uint8, device=device)
+    return workspace, workspace.numel() * workspace.element_size()
+
+
+def dropout_bwd_cast(dx, drop: Dropout, g, colsum=None, workspace=None):
+    """colsum (optional) is overwritten; workspace: colsum_workspace(M, N) bytes (allocated here if None)."""
+    require_cuda(dx, g, colsum, workspace)
     M, N = dx.shape
     assert dx.dtype == torch.float32 and dx.is_contiguous() and g.is_contiguous()
-    check(_lib.load().capdec_dropout_bwd_cast(ptr(dx), M, N, drop, ptr(g), dtype_code(g), ptr(colsum), _st()), "capdec_dropout_bwd_cast")
+    wsb = 0
+    if colsum is not None:
+        workspace, wsb = _colsum_ws(workspace, M, N, dx.device)
+    check(_lib.load().capdec_dropout_bwd_cast(ptr(dx), M, N, drop, ptr(g), dtype_code(g), ptr(colsum), ptr(workspace), wsb, _st()),
+          "capdec_dropout_bwd_cast")
 
 
-def colsum(x, out):
-    require_cuda(x, out)
+def colsum(x, out, workspace=None):
+    """out[n] = sum_m x[m, n] (overwritten, deterministic)."""
+    require_cuda(x, out, workspace)
     M, N = x.shape
-    check(_lib.load().capdec_colsum(ptr(x), dtype_code(x), M, N, _ld(x), ptr(out), _st()), "capdec_colsum")
+    workspace, wsb = _colsum_ws(workspace, M, N, x.device)
+    check(_lib.load().capdec_colsum(ptr(x), dtype_code(x), M, N, _ld(x), ptr(out), ptr(workspace), wsb, _st()), "capdec_colsum")
 
 
 def embed_rows(table, ids, out, pos_row=None):

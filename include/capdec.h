@@ -59,25 +59,34 @@ int capdec_dropout_mask(capdec_dropout d, long n, float* out, void* stream);
  * decoder.py:53 (norm1).  img [B,P,d], sos [B,1,d], cap [B,L,d] of `in_dtype`;
  * optional pos [S,d] f32 added per row (no reference counterpart).
  * Writes x [S*B,d] f32 (the residual stream), y = LN(x) of `y_dtype`,
- * mean/rstd [S*B] f32.  Any of x / y / mean / rstd may be NULL (y NULL = join only). */
+ * mean/rstd [S*B] f32.  Any of x / y / mean / rstd may be NULL (y NULL = join only).
+ * Rows of x below x_row0 are NOT written (a caller that needs the residual only for the
+ * scored rows saves that traffic; pass 0 to keep every row). */
 int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int in_dtype,
                          const float* pos, const float* gamma, const float* beta, float eps,
                          int B, int P, int L, int d,
-                         float* x, void* y, int y_dtype, float* mean, float* rstd, void* stream);
+                         float* x, long x_row0, void* y, int y_dtype, float* mean, float* rstd, void* stream);
 
 /* decoder.py:53,58 (nn.LayerNorm, eps 1e-5): y = LN(x) for x [M,d] f32. */
 int capdec_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int d,
                   void* y, int y_dtype, float* mean, float* rstd, void* stream);
 
 /* Backward of the above (autograd of decoder.py:53,58).  dy [M,d] of dy_dtype.
- * dx_out = dx_in (may be NULL = 0) + dLN/dx; dx_out may alias dx_in.
- * dgamma/dbeta [d] f32 are OVERWRITTEN.  partial: scratch of
+ * dx_out = dx_in (may be NULL = 0) + dLN/dx; dx_out may alias dx_in; dx_out NULL = only the
+ * affine gradients are computed.  dgamma/dbeta [d] f32 are OVERWRITTEN.  partial: scratch of
  * capdec_ln_bwd_workspace(M,d) bytes. */
 long capdec_ln_bwd_workspace(long M, int d);
 int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                   const float* mean, const float* rstd, long M, int d,
                   const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
                   void* partial, void* stream);
+/* Affine gradients of the LayerNorm that capdec_concat_ln_fwd applied (decoder.py:53 on the
+ * joined rows of img_text_concat.py:115-123), reading the rows again from img / sos / cap
+ * (+ pos) instead of a kept copy of the joined tensor.  dy [(P+1+L)*B, d]; mean/rstd as written
+ * by the forward; dgamma/dbeta OVERWRITTEN; partial as for capdec_ln_bwd with M = (P+1+L)*B. */
+int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const void* img, const void* sos, const void* cap, int in_dtype,
+                                const float* pos, const float* gamma, const float* mean, const float* rstd,
+                                int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, void* stream);
 
 /* ------------------------------------------------------------------ GEMM + fused epilogue
  * C[m,n] = epilogue( sum_k A(m,k) * B(n,k) ).  Replaces every nn.Linear of
@@ -198,13 +207,18 @@ int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dt
 /* ------------------------------------------------------------------ element-wise helpers */
 /* dst = cast(src) for n elements */
 int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* Column sums are computed in two deterministic stages (row stripes, then a fixed-order fold) and
+ * need a scratch buffer of capdec_colsum_workspace(M,N) bytes. */
+long capdec_colsum_workspace(long M, int N);
 /* Backward of `x + dropout(y)` w.r.t. y (decoder.py:55,63): g[m,n] = dx[m,n] * keep / (1-p)
- * cast to g_dtype; colsum[n] (optional, f32, atomic +=) receives the column sums
- * (= bias gradient of the Linear that produced y). */
+ * cast to g_dtype; colsum[n] (optional, f32, OVERWRITTEN) receives the column sums of g
+ * (= bias gradient of the Linear that produced y); workspace only needed with colsum. */
 int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
-                            void* g, int g_dtype, float* colsum, void* stream);
-/* colsum[n] += sum_m x[m,n]  (bias gradients) */
-int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream);
+                            void* g, int g_dtype, float* colsum,
+                            void* workspace, long workspace_bytes, void* stream);
+/* colsum[n] = sum_m x[m,n]  (bias gradients; OVERWRITTEN) */
+int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum,
+                  void* workspace, long workspace_bytes, void* stream);
 /* rows of a token-embedding table: out[i,:] = table[ids[i],:] (+ pos row if given); out f32 */
 int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
                       float* out, void* stream);

@@ -247,6 +247,18 @@ def test_concat_ln_fwd_bwd(ydt, d):
     close(dx, xg.grad + dx_in, 1e-5, "dx")
     close(dg, gg.grad, 1e-5, "dgamma")
     close(db, bg.grad, 1e-5, "dbeta")
+    # affine gradients only: from the kept rows, and from the sources of the join
+    dg2, db2 = torch.full((d,), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
+    ops.ln_bwd(dy, x, gamma, mean, rstd, None, None, dg2, db2, ws)
+    assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    dg3, db3 = torch.full((d,), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
+    ops.concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dg3, db3, ws, pos=pos)
+    assert torch.equal(dg3, dg) and torch.equal(db3, db)
+    # the joined rows below x_row0 are not written
+    x2 = torch.full_like(x, float("nan"))
+    y3 = torch.empty_like(y)
+    ops.concat_ln_fwd(img, sos, cap, gamma, beta, pos=pos, x_out=x2, x_row0=P * B + 2, y_out=y3, mean=mean, rstd=rstd)
+    assert torch.equal(y3, y) and torch.equal(x2[P * B + 2:], x[P * B + 2:]) and bool(torch.isnan(x2[:P * B + 2]).all())
 
 
 # ---------------------------------------------------------------------------- attention
@@ -404,14 +416,24 @@ def test_elementwise_and_adam():
     drop = ops.dropout_keys(9, 4, 2, p=0.1)
     keep = ops.dropout_mask(drop, M * N, DEV).reshape(M, N)
     g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    cs = torch.zeros(N, device=DEV)
+    cs = torch.full((N,), float("nan"), device=DEV)                 # column sums are overwritten, not accumulated
     ops.dropout_bwd_cast(dx, drop, g, cs)
     ref = dx * keep / 0.9
     close(g, ref, 1e-2, "dropout_bwd_cast")
     close(cs, ref.sum(0), 1e-5, "colsum of dropout_bwd_cast")
-    cs2 = torch.zeros(N, device=DEV)
+    cs2 = torch.full((N,), float("nan"), device=DEV)
     ops.colsum(g, cs2)
     close(cs2, g.float().sum(0), 1e-5, "colsum")
+    # many stripes, a strided view, ragged width; twice the same bits (fixed summation order)
+    big = rnd(5000, 350, seed=52).to(torch.bfloat16)
+    view = big[7:, 3:340]
+    c3, c4 = torch.empty(337, device=DEV), torch.empty(337, device=DEV)
+    ops.colsum(view, c3)
+    ops.colsum(view, c4)
+    close(c3, view.float().sum(0), 1e-5, "colsum of a strided view")
+    assert torch.equal(c3, c4)
+    with pytest.raises(RuntimeError, match="workspace"):
+        ops.colsum(big, torch.empty(350, device=DEV), workspace=torch.empty(64, dtype=torch.uint8, device=DEV))
     b = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     ops.cast(dx, b)
     assert torch.equal(b, dx.to(torch.bfloat16))
