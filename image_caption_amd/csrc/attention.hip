@@ -1,14 +1,16 @@
 // Self-attention for the captioning decoder (gfx950).
 //
-// Training / prefill (bf16): one workgroup per (sequence, head, 64-query slab);
-// the sequence's whole K and V ([S,hd], S <= 384) sit in LDS, each wave owns 16
-// queries and walks the keys in blocks of 64 with an online softmax.  Scores are
-// computed transposed (S^T = K Q^T) so that a lane holds 4 consecutive keys of
-// ONE query: the probabilities are then already the B operand of the next MFMA
-// (O^T = V^T P^T) and V^T comes from LDS through the transposing read; nothing
-// but K and V ever touches LDS.  The backward uses the same trick twice: a
-// query-major kernel for dQ and a key-major kernel for dK/dV, both recomputing
-// P from the saved log-sum-exp.
+// Training / prefill (bf16): one workgroup per (sequence, head, slab of up to 64
+// queries); each wave owns 16 queries and walks the keys in blocks of 64 with an
+// online softmax.  Scores are computed transposed (S^T = K Q^T) so that a lane
+// holds 4 consecutive keys of ONE query: the probabilities are then already the
+// B operand of the next MFMA (O^T = V^T P^T).  Only the operand that is consumed
+// TRANSPOSED sits in LDS (the sequence's whole V, [S,hd], S <= 768 at hd 96, read
+// back with the transposing LDS read); K is a row-major operand, whose fragments
+// are 16 contiguous bytes per lane and come straight from global memory, one key
+// block ahead of their use.  The backward uses the same trick twice: a
+// query-major kernel for dQ (K in LDS, V direct; it also produces delta = rowsum(dO*O))
+// and a key-major kernel for dK/dV, both recomputing P from the saved log-sum-exp.
 // Validation (f32): simple exact-f32 kernels with the same interface.
 // Decoding: one query row against a contiguous K/V cache, HBM-bound.
 #include "common.h"
@@ -40,16 +42,47 @@ template <int HD> struct Geo {
     static constexpr int CPR = HD / 8;         // 16-B chunks per row
 };
 
-// rows [row0, row0+nvalid) of a strided [*, HD] bf16 matrix -> LDS, zero rows up to npad
+// rows [row0, row0+nvalid) of a strided [*, HD] bf16 matrix -> LDS, zero rows up to npad;
+// four 16-byte loads per thread are in flight before the first LDS write
 template <int HD>
 __device__ __forceinline__ void rows_to_lds(char* lds, const bf16_t* base, long sstride, int row0, int nvalid, int npad,
                                             int tid, int nthreads) {
     constexpr int CPR = Geo<HD>::CPR, ROWB = Geo<HD>::ROWB;
-    for (int c = tid; c < npad * CPR; c += nthreads) {
-        const int row = c / CPR, ch = c - row * CPR;
-        u32x4 v = u32x4{0, 0, 0, 0};
-        if (row < nvalid) v = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * sstride + ch * 8);
-        *reinterpret_cast<u32x4*>(lds + row * ROWB + ch * 16) = v;
+    const int total = npad * CPR;
+    for (int c0 = tid; c0 < total; c0 += 4 * nthreads) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * nthreads;
+            const int row = c / CPR, ch = c - row * CPR;
+            v[u] = u32x4{0, 0, 0, 0};
+            if (c < total && row < nvalid) v[u] = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * sstride + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * nthreads;
+            const int row = c / CPR, ch = c - row * CPR;
+            if (c < total) *reinterpret_cast<u32x4*>(lds + row * ROWB + ch * 16) = v[u];
+        }
+    }
+}
+
+// the 4 x KS row-major fragments of a 64-row block of a [S, HD] matrix, straight from global memory:
+// lane (g,i) of tile t gets M[row0 + 16t + i][32ks + 8g .. +7] (zero past S)
+template <int HD>
+__device__ __forceinline__ void frags_from_global(const bf16_t* base, long sstride, int row0, int S, int lane,
+                                                  bf16x8 (&f)[4][Geo<HD>::KS]) {
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = row0 + t * 16 + i;
+#pragma unroll
+        for (int ks = 0; ks < Geo<HD>::KS; ++ks) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+            f[t][ks] = row < S ? *reinterpret_cast<const bf16x8*>(base + (long)row * sstride + ks * 32 + 8 * g) : z;
+        }
     }
 }
 
@@ -88,12 +121,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
-    char* Kl = smem;
-    char* Vl = smem + SP * G::ROWB;
-    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, 256);
-    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, 256);
+    const int nthreads = blockDim.x;
+    char* Vl = smem;
+    const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
+    bf16x8 kf[4][G::KS];
+    frags_from_global<HD>(kbase, p.k_ss, 0, p.S, lane, kf);       // first key block, in flight during the staging of V
+    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
     __syncthreads();
-    const int qw = p.q_start + blockIdx.y * 64 + wave * 16;       // first query of this wave
+    const int qw = p.q_start + blockIdx.y * (nthreads >> 2) + wave * 16;       // first query of this wave
     const int qend = min(p.q_start + p.nq, p.S);
     if (qw >= qend) return;
     const int q = qw + i;
@@ -109,13 +144,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
     const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
 
     for (int kb = 0; kb < SP; kb += 64) {
+        bf16x8 kn[4][G::KS];
+        if (kb + 64 < SP) frags_from_global<HD>(kbase, p.k_ss, kb + 64, p.S, lane, kn);      // next key block
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+        }
+        if (kb + 64 < SP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) kf[t][ks] = kn[t][ks];
         }
         float bm = -INFINITY;
 #pragma unroll
@@ -177,32 +220,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
+    const int nthreads = blockDim.x;
     char* Kl = smem;
-    char* Vl = smem + SP * G::ROWB;
-    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, 256);
-    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, 256);
+    const bf16_t* vbase = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs;
+    bf16x8 vf[4][G::KS];
+    frags_from_global<HD>(vbase, p.v_ss, 0, p.S, lane, vf);       // V is only a row-major operand here: no LDS copy
+    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, nthreads);
     __syncthreads();
-    const int qw = p.q_start + blockIdx.y * 64 + wave * 16;
+    const int qw = p.q_start + blockIdx.y * (nthreads >> 2) + wave * 16;
     const int qend = min(p.q_start + p.nq, p.S);
     if (qw >= qend) return;
     const int q = qw + i;
     const bool qok = q < qend;
     const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
     const bf16_t* dorow = (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs + (long)q * p.do_ss;
+    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
     bf16x8 qf[G::KS], dof[G::KS];
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
         qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + 8 * g) : zero_frag();
         dof[ks] = qok ? *reinterpret_cast<const bf16x8*>(dorow + ks * 32 + 8 * g) : zero_frag();
+        const bf16x8 of = qok ? *reinterpret_cast<const bf16x8*>(orow + ks * 32 + 8 * g) : zero_frag();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)dof[ks][e] * (float)of[e];
     }
     const float lse = qok ? p.lse[(long)bh * p.S + q] : 0.f;
-    const float delta = qok ? p.delta[(long)bh * p.S + q] : 0.f;
+    // delta = rowsum(dO * O): the four lanes (g) of a query hold disjoint quarters of its row
+    const float delta = quad_sum(dsum);
+    if (qok && g == 0) p.delta[(long)bh * p.S + q] = delta;       // the key-major kernel reads it
     const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
     f32x4 acc[G::DT];
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
 
     for (int kb = 0; kb < SP; kb += 64) {
+        bf16x8 vn[4][G::KS];
+        if (kb + 64 < SP) frags_from_global<HD>(vbase, p.v_ss, kb + 64, p.S, lane, vn);      // next key block of V
         bf16x8 dsf[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -210,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Vl, kb + t * 16, ks * 32, lane), dof[ks], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -228,6 +282,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
             for (int dt = 0; dt < G::DT; ++dt)
                 acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
+        if (kb + 64 < SP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) vf[t][ks] = vn[t][ks];
+        }
     }
     if (qok) {
         bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
@@ -607,9 +667,10 @@ extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
                      (a.o_bs % 4) == 0 && (a.o_hs % 4) == 0 && (a.o_ss % 4) == 0 && aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.o),
                      "attn_fwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
         const int SP = (a.S + 63) & ~63;
-        const int lds = 2 * SP * (a.hd * 2 + 16);
-        CAPDEC_CHECK(lds <= 160 * 1024, "attn_fwd(bf16): sequence %d too long for the LDS-resident K/V design (hd=%d)", a.S, a.hd);
-        dim3 grid(a.B * a.H, (a.nq + 63) / 64), block(256);
+        const int lds = SP * (a.hd * 2 + 16);
+        CAPDEC_CHECK(lds <= 160 * 1024, "attn_fwd(bf16): sequence %d too long for the LDS-resident V design (hd=%d)", a.S, a.hd);
+        const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;        // a wave per 16 queries, at most 4 per workgroup
+        dim3 grid(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), block(64 * nwaves);
         HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD>, lds); hipLaunchKernelGGL(attn_fwd_mfma<HD>, grid, block, lds, st, a));
     } else {
         const int lds = (a.hd + a.S) * 4;
@@ -633,10 +694,9 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
     a.dq_scale = d->dq_scale; a.delta = d->delta;
     hipStream_t st = (hipStream_t)stream;
     const long nrow = (long)a.B * a.H * a.nq;
-    if (a.nq > 0) {
-        if (d->fwd.dtype == CAPDEC_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, a);
-    }
+    // delta = rowsum(dO * O): the bf16 query-major kernel produces it itself
+    if (a.nq > 0 && d->fwd.dtype != CAPDEC_BF16)
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, a);
     if (d->fwd.dtype == CAPDEC_BF16) {
         CAPDEC_CHECK(strides_ok8(a.q_bs, a.q_hs, a.q_ss) && strides_ok8(a.k_bs, a.k_hs, a.k_ss) && strides_ok8(a.v_bs, a.v_hs, a.v_ss) &&
                      strides_ok8(a.do_bs, a.do_hs, a.do_ss) && (a.dq_bs % 4) == 0 && (a.dq_hs % 4) == 0 && (a.dq_ss % 4) == 0 &&
@@ -644,14 +704,15 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
                      aligned16(a.dout) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv),
                      "attn_bwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
         const int SP = (a.S + 63) & ~63;
-        const int lds_q = 2 * SP * (a.hd * 2 + 16);
+        const int lds_q = SP * (a.hd * 2 + 16);
         const int NQP = (a.nq + 31) & ~31;
         const int lds_k = 2 * NQP * (a.hd * 2 + 16) + 2 * NQP * 4;
         CAPDEC_CHECK(lds_q <= 160 * 1024 && lds_k <= 160 * 1024, "attn_bwd(bf16): sequence %d too long for the LDS-resident design (hd=%d)", a.S, a.hd);
         dim3 block(256);
         if (a.nq > 0) {
-            dim3 gq(a.B * a.H, (a.nq + 63) / 64);
-            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD>, lds_q); hipLaunchKernelGGL(attn_bwd_dq_mfma<HD>, gq, block, lds_q, st, a));
+            const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;
+            dim3 gq(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), bq(64 * nwaves);
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD>, lds_q); hipLaunchKernelGGL(attn_bwd_dq_mfma<HD>, gq, bq, lds_q, st, a));
         }
         dim3 gk(a.B * a.H, (a.S + 63) / 64);
         HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD>, lds_k); hipLaunchKernelGGL(attn_bwd_dkv_mfma<HD>, gk, block, lds_k, st, a));

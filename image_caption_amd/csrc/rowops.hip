@@ -209,7 +209,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* part
 int ln_bwd_blocks(long M) {
     long nb = (M + 31) / 32;       // >= 8 rows per wave
     if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
+    if (nb > 512) nb = 512;        // two blocks per CU; the finalize pass reads one partial row per block
     return (int)nb;
 }
 
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(1024) void stripe_fold_kernel(const float* partial,
     }
 }
 
-// rows per stripe: about 512 stripes, at least 16 rows each, a multiple of the 4 row lanes
+// rows per stripe: about 256 stripes, at least 16 rows each, a multiple of the 4 row lanes
 int colsum_stripe_rows(long M) {
-    long r = (M + 511) / 512;
+    long r = (M + 255) / 256;
     if (r < 16) r = 16;
     return (int)((r + 3) / 4 * 4);
 }
