@@ -48,56 +48,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* 
                                                       long M, int B, int P, int L, int d,
                                                       float* xout, long x_row0, TOUT* y, float* mean, float* rstd) {
     const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= M) return;
-    if (r < x_row0) xout = nullptr;          // the joined row itself is only kept from x_row0 on
-    f32x4 v[LN_VEC];
-    float sum = 0.f;
-    long s = 0;
-    const TIN* src = nullptr;
-    if constexpr (CONCAT) {
-        s = r / B;
-        const long b = r - s * B;
-        src = s < P ? img + (b * P + s) * d : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
-    }
+    const long nwaves = (long)gridDim.x * 4;
+    // a wave walks rows r, r + nwaves, ...: long-lived waves keep more bytes in flight than one wave per row
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += nwaves) {
+        float* xo = r < x_row0 ? nullptr : xout;          // the joined row itself is only kept from x_row0 on
+        f32x4 v[LN_VEC];
+        float sum = 0.f;
+        long s = 0;
+        const TIN* src = nullptr;
+        if constexpr (CONCAT) {
+            s = r / B;
+            const long b = r - s * B;
+            src = s < P ? img + (b * P + s) * d : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
+        }
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
-        const int c = lane * 4 + i * 256;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < d) {
-            if constexpr (CONCAT) {
-                v[i] = load4<TIN>(src + c);
-                if (pos) v[i] += *reinterpret_cast<const f32x4*>(pos + s * d + c);
-                if (xout) *reinterpret_cast<f32x4*>(xout + r * d + c) = v[i];
-            } else {
-                v[i] = *reinterpret_cast<const f32x4*>(xin + r * d + c);
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int c = lane * 4 + i * 256;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < d) {
+                if constexpr (CONCAT) {
+                    v[i] = load4<TIN>(src + c);
+                    if (pos) v[i] += *reinterpret_cast<const f32x4*>(pos + s * d + c);
+                    if (xo) *reinterpret_cast<f32x4*>(xo + r * d + c) = v[i];
+                } else {
+                    v[i] = *reinterpret_cast<const f32x4*>(xin + r * d + c);
+                }
+                sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             }
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
-    }
-    if (!y) return;
-    const float mu = wave_sum(sum) / d;
-    float sq = 0.f;
+        if (!y) continue;
+        const float mu = wave_sum(sum) / d;
+        float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (c < d) {
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+            }
         }
-    }
-    const float rs = rsqrtf(wave_sum(sq) / d + eps);
-    if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+        const float rs = rsqrtf(wave_sum(sq) / d + eps);
+        if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (c < d) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
-            f32x4 o;
+        for (int i = 0; i < LN_VEC; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+                f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
-            store4<TOUT>(y + r * d + c, o);
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
+                store4<TOUT>(y + r * d + c, o);
+            }
         }
     }
 }
@@ -375,7 +377,8 @@ template <typename TIN, typename TOUT, bool CONCAT>
 static void launch_ln_fwd(const void* img, const void* sos, const void* cap, const float* xin, const float* pos,
                           const float* gamma, const float* beta, float eps, long M, int B, int P, int L, int d,
                           float* xout, long x_row0, void* y, float* mean, float* rstd, hipStream_t st) {
-    hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
+    const long nblk = (M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048;       // 8 workgroups per CU, each wave walks several rows
+    hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)nblk), dim3(256), 0, st,
                        (const TIN*)img, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
                        xout, x_row0, (TOUT*)y, mean, rstd);
 }

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the HBM-bound row kernels of one training step at batch 256, each with
+the bytes it must move and the bandwidth that implies.  Usage (GPU box): python tools/rowops_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_caption_amd import ops  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    B, P, L, d = 256, 196, 32, 768
+    S = P + 1 + L
+    M, Mt = S * B, L * B
+    g = torch.Generator(device=DEV).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)       # noqa: E731
+    img, sos, cap = r(B, P, d), r(B, 1, d), r(B, L, d)
+    gamma, beta = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    x = torch.empty(M, d, device=DEV)
+    h1 = torch.empty(M, d, device=DEV, dtype=BF)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    rows = []
+
+    def add(name, nbytes, fn):
+        ms = timeit(fn)
+        rows.append((name, ms * 1e3, nbytes / ms / 1e6))
+
+    add("join + LayerNorm fwd (x kept for the scored rows)", M * d * 4 + M * d * 2 + Mt * d * 4,
+        lambda: ops.concat_ln_fwd(img, sos, cap, gamma, beta, x_out=x, x_row0=M - Mt, y_out=h1, mean=mean, rstd=rstd))
+    ops.concat_ln_fwd(img, sos, cap, gamma, beta, x_out=x, y_out=h1, mean=mean, rstd=rstd)
+    add("LayerNorm fwd of contiguous f32 rows", M * d * 4 + M * d * 2, lambda: ops.ln_fwd(x, gamma, beta, h1, mean, rstd))
+    dy = r(M, d).to(BF)
+    dg, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    ws = torch.empty(ops.ln_bwd_workspace(M, d), dtype=torch.uint8, device=DEV)
+    add("LayerNorm bwd, affine only, rows from the join sources", M * d * 4 + M * d * 2,
+        lambda: ops.concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dg, db, ws))
+    add("LayerNorm bwd, affine only, contiguous rows", M * d * 4 + M * d * 2, lambda: ops.ln_bwd(dy, x, gamma, mean, rstd, None, None, dg, db, ws))
+    dkv = r(M, 2 * d).to(BF)
+    cs = torch.empty(2 * d, device=DEV)
+    cws = torch.empty(ops.colsum_workspace(M, 2 * d), dtype=torch.uint8, device=DEV)
+    add("column sums of dK|dV [58624 x 1536] bf16", M * 2 * d * 2, lambda: ops.colsum(dkv, cs, cws))
+    dx = r(Mt, d)
+    g2 = torch.empty(Mt, d, device=DEV, dtype=BF)
+    cs2 = torch.empty(d, device=DEV)
+    drop = ops.dropout_keys(1, 2, 3, 0.1)
+    add("dropout bwd + cast + column sums [8192 x 768]", Mt * d * 6, lambda: ops.dropout_bwd_cast(dx, drop, g2, cs2, cws))
+    n = 42_700_000
+    w, gr, m, v = (torch.zeros(n, device=DEV) for _ in range(4))
+    sh = torch.empty(n, device=DEV, dtype=BF)
+    add("Adam over 42.7 M parameters (+ bf16 shadow)", n * 30, lambda: ops.adam_step(w, gr, m, v, 1, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, sh))
+    for name, us, gbs in rows:
+        print(f"{name:58s} {us:8.1f} us  {gbs:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
