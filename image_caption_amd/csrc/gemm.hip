@@ -58,15 +58,19 @@ struct GemmArgs {
 
 // ------------------------------------------------------------------ tile order
 // Blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
-// run of logical tile ids (bijective for any grid size), and walk those ids in
-// groups of 8 M-tiles x all N-tiles so that co-resident tiles share operand panels
-// in that XCD's L2.
+// run of logical tile ids (bijective for any grid size).  About 64 consecutive ids
+// are resident on an XCD at a time and should share operand panels in its L2:
+// with many N-tiles the ids walk groups of 8 M-tiles x all N-tiles (an 8 x 8 block
+// is resident); with at most 16 N-tiles they walk N fastest, so that every resident
+// M-tile has ALL its N-tiles resident and its A panel -- the large streamed operand
+// of the dgrad / wgrad products, d(logits) -- leaves HBM once instead of once per
+// residency window.
 __device__ __forceinline__ void map_tile(int tm, int tn, int& tile_m, int& tile_n) {
     const int nwg = tm * tn;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GROUP = 8;
+    const int GROUP = tn <= 16 ? 1 : 8;
     const int per_group = GROUP * tn;
     const int grp = logical / per_group;
     const int first_m = grp * GROUP;
@@ -672,7 +676,7 @@ __device__ __forceinline__ int dlds_rowmajor(int row, int kc) { return row * 64 
 template <bool TR>
 __device__ __forceinline__ bf16x8 dread_frag(const char* tile, int rb, int lane) {
     if constexpr (!TR) return *reinterpret_cast<const bf16x8*>(tile + dlds_rowmajor(rb + (lane & 15), lane >> 4));
-    else return read_frag<true>(tile, rb, 0, lane);
+    else return read_frag<true>(tile + (rb >> 7) * DTILE_BYTES, rb & 127, 0, lane);
 }
 
 // byte offset (from the k-tile's base) a lane fetches for 1-KiB piece `piece` of a tile image
@@ -683,9 +687,11 @@ __device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int pie
         const int kc = pc ^ (((row >> 3) & 1) * 3);
         return (unsigned)(((long)row * v.ld + kc * 8) * 2);
     } else {
-        const int krow = 4 * piece + (lane >> 4), pc = lane & 15;
-        const int chunk = pc ^ (kswz(krow) << 1);
-        return chunk * 8 < v.rows_left ? (unsigned)(((long)krow * v.ld + chunk * 8) * 2) : 0xFFFFFFFFu;
+        // a reduction-major tile wider than 128 columns is a row of 8-KiB sub-images of 128 columns each
+        const int sub = piece >> 3, pp = piece & 7;
+        const int krow = 4 * pp + (lane >> 4), pc = lane & 15;
+        const int col = sub * 128 + (pc ^ (kswz(krow) << 1)) * 8;
+        return col < v.rows_left ? (unsigned)(((long)krow * v.ld + col) * 2) : 0xFFFFFFFFu;
     }
 }
 
@@ -718,7 +724,7 @@ __device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned* o
 //            reads than 128x128 (whose 16 KiB per 32-deep step needs the CU's whole 64 B/clk fill path),
 //            and the co-resident workgroup's main loop covers this one's epilogue
 //   <4,4,4>  256x128, 8 waves of 64x64, 1 workgroup/CU
-// A row-major only beyond 128 rows (a reduction-major A image has 128-column rows).
+// A reduction-major A image wider than 128 columns is stored as two 128-column sub-images.
 template <int WM, int TI, int NST> struct DmaGeo {
     static constexpr int NW = 2 * WM;                       // waves
     static constexpr int WROWS = 16 * TI;                   // rows per wave
@@ -738,7 +744,6 @@ template <bool A_TR, bool B_TR, int EPI, int WM, int TI, int NST>
 __global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void gemm_bf16_dma_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = DmaGeo<WM, TI, NST>;
-    static_assert(G::BMV == 128 || !A_TR, "tiles taller than 128 rows need a row-major A");
     const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + BN - 1) / BN;
     int tile_m, tile_n;
     map_tile(tm, tn, tile_m, tile_n);
@@ -927,9 +932,10 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         CAPDEC_CHECK(aligned16(a.A) && aligned16(a.B), "gemm(bf16): A/B must be 16-byte aligned");
         // Kernel choice.  The LDS-DMA ring needs whole 32-deep k-tiles, except when both operands are
         // reduction-major (their k-tail lies past the end of the buffer descriptor and reads as zero).
-        // Row-major products always take it, and so does a reduction-major B (dgrad) when the 256-row
-        // geometry applies (row-major A, at least one workgroup per CU).  A reduction-major A (wgrad)
-        // stays on the register-staged kernel, which measured faster on those shapes.
+        // Row-major products always take it; with reduction-major operands (two transposing LDS reads per
+        // fragment) it wins where the grid is large and K deep (the vocabulary-sized dgrad / wgrad), while
+        // the small split-K weight gradients of the block measured faster on the register-staged kernel.
+        // The 256-row geometry needs at least one workgroup per CU.
         enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG };
         const bool any_km = a.a_kmajor || a.b_kmajor;
         const bool ring_ok = a.K >= DBK && ((a.K % DBK) == 0 || (a.a_kmajor && a.b_kmajor));
@@ -938,12 +944,15 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         int kern = KERN_REG;
         if (ring_ok && !a.a_kmajor) {
             if (big_tiles * split >= 256 && (!a.b_kmajor || a.K >= 512)) kern = KERN_TALL;
-            else if (!a.b_kmajor) kern = KERN_RING128;
+            else if (!a.b_kmajor || (a.K >= 2048 && split == 1)) kern = KERN_RING128;
+        } else if (ring_ok) {
+            if (big_tiles >= 512) kern = KERN_TALL;
+            else if (nwg >= 256 && a.K >= 2048 && split == 1) kern = KERN_RING128;
         }
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
-        else if (g_gemm_mode == 4 && ring_ok && !a.a_kmajor) kern = KERN_TALL;
+        else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
 #define CAPDEC_RING_LAUNCH(AT, BT, WM, TI, NST, NWG)                                                   \
     do {                                                                                               \
         using G = DmaGeo<WM, TI, NST>;                                                                 \
@@ -969,7 +978,9 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         }                                                                                              \
     } while (0)
         if (kern == KERN_TALL) {
-            if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 8, 3, big_tiles);
+            if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 8, 3, big_tiles);
+            else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 8, 3, big_tiles);
+            else if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 8, 3, big_tiles);
             else CAPDEC_RING_LAUNCH(false, false, 2, 8, 3, big_tiles);
         } else if (kern == KERN_BIG) CAPDEC_RING_LAUNCH(false, false, 4, 4, 4, big_tiles);
         else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
