@@ -86,6 +86,22 @@ def cpu_baseline(max_seconds=25.0):
                       f"Adam wd 0.01), median {med * 1e3:.0f} ms/step, f32, torch {torch.__version__}"}
 
 
+def pmc_traffic(span, args, B, whole_vocab):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot be collected inside this process); None unless this run has the configuration the
+    counters were collected on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    on = doc.get("collected_on", {})
+    same = (on.get("per_gpu_batch") == B and on.get("dtype") == args.dtype and on.get("n_blocks") == args.n_blocks
+            and on.get("patches") == args.patches and whole_vocab and not args.all_rows)
+    rec = doc.get("launches", {}).get(span)
+    return rec["hbm_bytes_per_launch"] if same and rec else None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -154,10 +170,10 @@ def main():
                  "logits_ce_bwd_slab": 2.0 * Mh * d * min(slab, V),
                  "head_dgrad_slab": 2.0 * Mh * d * min(slab, V),
                  "head_wgrad_slab": 2.0 * Mh * d * min(slab, V)}
-        kernel_names = {"logits_ce_fwd": "gemm_bf16_kernel<false,false,EPI_CE_FWD>",
-                        "logits_ce_bwd_slab": "gemm_bf16_kernel<false,false,EPI_CE_BWD>",
-                        "head_dgrad_slab": "gemm_bf16_kernel<false,true,EPI_STD>",
-                        "head_wgrad_slab": "gemm_bf16_kernel<true,true,EPI_STD>"}
+        kernel_names = {"logits_ce_fwd": "gemm_bf16_dma_kernel<false,false,1,2,8,3> (EPI_CE_FWD) + ce_finalize_kernel",
+                        "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,8,3> (EPI_CE_BWD) + colpart_reduce_kernel",
+                        "head_dgrad_slab": "gemm_bf16_dma_kernel<false,true,0,2,8,3> (EPI_STD, split-K) + splitk_reduce_kernel",
+                        "head_wgrad_slab": "gemm_bf16_dma_kernel<true,true,0,2,8,3> (EPI_STD)"}
         per_kernel = {}
         for name, (count, ms) in spans.items():
             if name in flops and ms > 0:
@@ -172,7 +188,8 @@ def main():
         if dom:
             a = per_kernel[dom]["tflops"]
             roofline = {"kernel": kernel_names[dom], "bound": "mfma", "achieved": a, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                        "traffic": pmc_traffic(dom, args, B, slab >= V),
                         "ms_per_launch": per_kernel[dom]["ms_per_launch"], "per_kernel": per_kernel,
                         "whole_step_algorithmic_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 1) if args.n_blocks == 1 and args.patches == 196 else None}
         result = {

@@ -53,6 +53,7 @@ class EngineOptions:
     activation: str = "relu"                      # decoder.py:60; "gelu" is an extension
     vocab_slab: int = 0                           # vocabulary columns per backward slab; 0: as wide as dl_budget_bytes allows
     dl_budget_bytes: int = 2 << 30                # cap on the d(logits) slab buffer (the whole vocabulary fits at batch 256)
+    wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     dropout_seed: int = 42
 
@@ -192,6 +193,8 @@ class DecoderEngine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self.cdt = self.opt.compute_dtype
         self.timer: Optional[KernelTimer] = None
+        self._side: Optional[torch.cuda.Stream] = None
+        self._side_used = False
 
     def _span(self, name: str):
         return self.timer.span(name) if self.timer is not None else contextlib.nullcontext()
@@ -209,6 +212,29 @@ class DecoderEngine:
         elif zero:
             t.zero_()
         return t
+
+    def _on_side_stream(self, fn):
+        """Runs fn (launches of kernels nothing downstream in this backward waits for: the block's
+        weight-gradient products) on a second stream, ordered after everything issued so far on the
+        current one.  Those products have few tiles and very deep K; next to them the dgrad chain and
+        the attention backward leave CUs idle.  _join_side_stream() orders the current stream after them."""
+        if not self.opt.wgrad_stream:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None or self._side.device != main.device:
+            self._side = torch.cuda.Stream(device=main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            fn()
+        self._side_used = True
+
+    def _join_side_stream(self):
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_used = False
 
     def _keys(self, site: int, step: int, train: bool):
         p = self.geo.dropout if train else 0.0
@@ -417,7 +443,7 @@ class DecoderEngine:
         # ---- MLP
         g2 = self.buf("g_res", (Mt, d), cdt, dev)
         ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
-        ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
+        self._on_side_stream(lambda: ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         if self.opt.activation == "relu":
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
@@ -425,16 +451,17 @@ class DecoderEngine:
         else:
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
                      gate_drop=k_h, colsum=G("linear1.bias"))
-        ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
+        self._on_side_stream(lambda: ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dh2 = self.buf("dh", (Mt, d), cdt, dev)
         ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
         dx_mid = self.buf(f"dx_mid", (Mt, d), torch.float32, dev)
         lnws = self.buf("ln_ws", (ops.ln_bwd_workspace(M, d),), torch.uint8, dev)
         ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
         # ---- attention
-        g1 = g2
+        g1 = self.buf("g_res1", (Mt, d), cdt, dev)        # not g2's buffer: a side-stream product may still read that
         ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"), csws)
-        ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
+        self._on_side_stream(lambda: ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True,
+                                              b_kmajor=True, workspace=skws))
         dattn = self.buf("dattn", (M, d), cdt, dev)
         ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
         dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
@@ -445,12 +472,15 @@ class DecoderEngine:
         h1 = sv["h1"]
         if q_start == 0:
             ops.colsum(dqkv, gin_b, csws)
-            ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
+            self._on_side_stream(lambda: ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
         else:
             ops.colsum(dqkv[r0:, :d], gin_b[:d], csws)
             ops.colsum(dqkv[:, d:], gin_b[d:], csws)
-            ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
-            ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
+
+            def in_proj_wgrads():
+                ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
+                ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
+            self._on_side_stream(in_proj_wgrads)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
         if not need_dx_in:
@@ -470,6 +500,7 @@ class DecoderEngine:
             else:
                 ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], None, None,
                            G("norm1.weight"), G("norm1.bias"), lnws)
+            self._join_side_stream()
             return None
         dh1 = self.buf("dh1", (M, d), torch.float32, dev)
         if q_start == 0:
@@ -484,6 +515,7 @@ class DecoderEngine:
             dres[r0:].copy_(dx_mid)
         dx_in = self.buf(f"dx_in.{i % 2}", (M, d), torch.float32, dev)
         ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
+        self._join_side_stream()
         return dx_in
 
     # ------------------------------------------------------------------ all-rows logits (the reference's forward)
