@@ -175,7 +175,16 @@ def main():
                         "head_dgrad_slab": "gemm_bf16_dma_kernel<false,true,0,2,8,3> (EPI_STD, split-K) + splitk_reduce_kernel",
                         "head_wgrad_slab": "gemm_bf16_dma_kernel<true,true,0,2,8,3> (EPI_STD)"}
         per_kernel = {}
+        esz = 2 if args.dtype == "bf16" else 4
+        Vp = (V + 127) // 128 * 128
+        hbm_kernels = {}
         for name, (count, ms) in spans.items():
+            if name == "ce_grad_from_probs" and ms > 0:
+                # HBM-bound pass: numerators read and d(logits) written in place, plus the forward's per-slot partials
+                nbytes = 2.0 * Mh * Vp * esz + 16.0 * Mh * 2 * ((V + 127) // 128)
+                hbm_kernels[name] = {"launches_per_step": count // max(1, args.steps), "ms_per_launch": round(ms, 4),
+                                     "algorithmic_gb": round(nbytes / 1e9, 3), "gb_per_s": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                     "frac_of_8tb_s": round(nbytes / (ms * 1e-3) / 8e12, 3)}
             if name in flops and ms > 0:
                 f = flops[name]
                 if name != "logits_ce_fwd":        # the last slab is narrower: use the mean slab width
@@ -190,7 +199,7 @@ def main():
             roofline = {"kernel": kernel_names[dom], "bound": "mfma", "achieved": a, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                         "traffic": pmc_traffic(dom, args, B, slab >= V),
-                        "ms_per_launch": per_kernel[dom]["ms_per_launch"], "per_kernel": per_kernel,
+                        "ms_per_launch": per_kernel[dom]["ms_per_launch"], "per_kernel": per_kernel, "hbm_bound_kernels": hbm_kernels,
                         "whole_step_algorithmic_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 1) if args.n_blocks == 1 and args.patches == 196 else None}
         result = {
             "metric": "train samples/sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,

@@ -100,7 +100,9 @@ SIGNATURES = {
     "capdec_logits_ce_workspace": (c_long, [c_long, c_int]),
     "capdec_logits_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_long, c_void_p]),
+                                     c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "capdec_logits_ce_bwd_from_probs": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_float,
+                                                c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                           c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int,
                                           c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),

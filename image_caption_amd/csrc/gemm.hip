@@ -357,10 +357,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 // lane -- no cross-lane traffic, no global loads, no bounds checks.  The maximum is tracked per 4-column
 // chunk (5 VALU ops per 4 columns) and the winning column is located inside the winning chunk afterwards.
 // The four results of a row go out as one 16-byte store, rows contiguous across lanes.
+template <int W, typename TO>
 __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, int mw, int nw, int slot, int lane) {
     const long m = (long)mw + lane;
     const bool live = m < p.M;
-    const float* row = cs + lane * CS_LD;
+    float* row = cs + lane * CS_LD;
     float m1 = -INFINITY;
     int ci = 0;
 #pragma unroll
@@ -382,19 +383,53 @@ __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, in
             for (int e = 0; e < 4; ++e) m2 = fmaxf(m2, nw + c4 * 4 + e == a1 ? -INFINITY : v[e]);
         }
     }
+    if (live && p.labels) {
+        const int lab = row_label(p, m) - nw;                // column of the label inside this slot, if 0..63
+        if (lab >= 0 && lab < 64) p.zlabel[m] = row[lab];
+    }
     float sum = 0.f;
     const float nref = m1 > -INFINITY ? -m1 * LOG2E : 0.f;
 #pragma unroll
     for (int c4 = 0; c4 < 16; ++c4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+        f32x4 ev;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, nref));
+        for (int e = 0; e < 4; ++e) { ev[e] = __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, nref)); sum += ev[e]; }
+        if (p.C) *reinterpret_cast<f32x4*>(row + c4 * 4) = ev;       // kept for the store pass below
     }
-    if (live) {
-        p.part4[(long)slot * p.M + m] = f32x4{m1, sum, m2, __int_as_float(a1)};
-        if (p.labels) {
-            const int lab = row_label(p, m) - nw;            // column of the label inside this slot, if 0..63
-            if (lab >= 0 && lab < 64) p.zlabel[m] = row[lab];
+    if (live) p.part4[(long)slot * p.M + m] = f32x4{m1, sum, m2, __int_as_float(a1)};
+    if (!p.C) return;
+    // exp(z - slot max), the numerators of the softmax, go out for the backward (which then needs no second
+    // product over the vocabulary): W consecutive columns per lane, one 16-byte store per row
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = 64 / W, RPI = 64 / LPR;
+    const int c = (lane % LPR) * W, g = lane / LPR;
+    const int n = nw + c;
+    if (n >= p.store_cols) return;
+    TO* C = (TO*)p.C;
+#pragma unroll 2
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int r = it * RPI + g;
+        const long mm = (long)mw + r;
+        if (mm >= p.M) continue;
+        const float* src = cs + r * CS_LD + c;
+        if constexpr (sizeof(TO) == 2) {
+            if constexpr (W == 8) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)a[e]; o[4 + e] = (bf16_t)b[e]; }
+                *reinterpret_cast<bf16x8*>(C + mm * p.ldc + n) = o;
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)a[e];
+                *reinterpret_cast<bf16x4*>(C + mm * p.ldc + n) = o;
+            }
+        } else {
+            *reinterpret_cast<f32x4*>(C + mm * p.ldc + n) = *reinterpret_cast<const f32x4*>(src);
         }
     }
 }
@@ -556,7 +591,11 @@ __device__ __forceinline__ void run_epilogue_at(const GemmArgs& p, float* cs, in
         else if (p.fast_epi == 4) epilogue_std_fast<4, float>(p, cs, mw, nw, lane);
         else epilogue_std<false>(p, cs, mw, nw, lane);
     } else if constexpr (EPI == EPI_STD_SIDE) epilogue_std<true>(p, cs, mw, nw, lane);
-    else if constexpr (EPI == EPI_CE_FWD) epilogue_ce_fwd(p, cs, mw, nw, slot, lane);
+    else if constexpr (EPI == EPI_CE_FWD) {
+        if (p.fast_epi == 8) epilogue_ce_fwd<8, bf16_t>(p, cs, mw, nw, slot, lane);
+        else if (p.out_dtype == CAPDEC_BF16) epilogue_ce_fwd<4, bf16_t>(p, cs, mw, nw, slot, lane);
+        else epilogue_ce_fwd<4, float>(p, cs, mw, nw, slot, lane);
+    }
     else {
         if (p.fast_epi == 8) epilogue_ce_bwd<8, bf16_t>(p, cs, mw, nw, lane);
         else if (p.out_dtype == CAPDEC_BF16) epilogue_ce_bwd<4, bf16_t>(p, cs, mw, nw, lane);
@@ -1100,6 +1139,99 @@ __global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* part,
     }
 }
 
+// d(logits) from the stored softmax numerators e = exp(z - slot max), in place:
+//   dl = e * exp(slot max - lse) * gscale - [column == label] * gscale.
+// A block owns 64 rows x 256 columns (4 slots): first one thread per (row, slot) forms the factor from
+// the forward's partials (rows contiguous across lanes), then a thread owns 8 columns of 8 rows.
+// Column sums of the block's 64 rows go to colpart[blockIdx.y][ld] (bias gradient, folded afterwards).
+template <typename T>
+__global__ __launch_bounds__(256) void ce_grad_from_probs_kernel(T* pd, long ld, long M, const f32x4* part4, int np, const float* lse,
+                                                                  const int64_t* labels, int ce_B, int ce_L, float gscale,
+                                                                  float* colpart, long ld_colpart) {
+    __shared__ float fs[4][64];
+    __shared__ int labs[64];
+    __shared__ float red[8][32][8];
+    const int t = threadIdx.x;
+    const long m0 = (long)blockIdx.y * 64;
+    const int n0 = blockIdx.x * 256;
+    {
+        const int r = t & 63, sl = t >> 6;
+        const long m = m0 + r;
+        const int slot = (n0 >> 6) + sl;
+        float f = 0.f;
+        if (m < M && slot < np) {
+            const float sm = part4[(long)slot * M + m][0];
+            if (sm > -INFINITY) f = __builtin_amdgcn_exp2f((sm - lse[m]) * LOG2E) * gscale;
+        }
+        fs[sl][r] = f;
+        if (sl == 0) {
+            int lab = -1 - n0;
+            if (m < M) { const long l = m / ce_B, b = m - l * ce_B; lab = (int)labels[b * ce_L + l] - n0; }
+            labs[r] = lab;
+        }
+    }
+    __syncthreads();
+    const int cc = t & 31, rg = t >> 5;
+    const long n = n0 + cc * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (n < ld) {
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int r = rg + 8 * i;
+            const long m = m0 + r;
+            if (m >= M) continue;
+            T* ptr = pd + m * ld + n;
+            float v[8];
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8 q = *reinterpret_cast<const bf16x8*>(ptr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)q[e];
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ptr), b = *reinterpret_cast<const f32x4*>(ptr + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            }
+            const float f = fs[cc >> 3][r];
+            const int lab = labs[r] - cc * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= f;
+            if ((unsigned)lab < 8u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] -= e == lab ? gscale : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x8*>(ptr) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(ptr) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(ptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+    }
+    if (!colpart) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][cc][e] = acc[e];
+    __syncthreads();
+    if (rg == 0 && n < ld) {
+        float s8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = acc[e];
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s8[e] += red[w][cc][e];
+        float* dst = colpart + (long)blockIdx.y * ld_colpart + n;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{s8[0], s8[1], s8[2], s8[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{s8[4], s8[5], s8[6], s8[7]};
+    }
+}
+
 // out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
@@ -1227,9 +1359,12 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
                                     long M, int V, int d, long ldh, long ldw,
                                     const int64_t* labels, int B, int L,
                                     float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                                    void* probs, long ld_probs,
                                     void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct, "logits_ce_fwd: null pointer");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd: M (%ld) must equal B*L", M);
+    CAPDEC_CHECK(!probs || (ld_probs >= V && (ld_probs % 8) == 0 && ld_probs <= (long)((V + BN - 1) / BN) * BN && aligned16(probs)),
+                 "logits_ce_fwd: ld_probs (%ld) must be a multiple of 8 in [V, roundup128(V)] and probs 16-byte aligned", ld_probs);
     CeWs ws;
     if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {
         capdec_set_error("logits_ce_fwd: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_workspace(M, V));
@@ -1237,7 +1372,8 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     }
     GemmArgs a;
     fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
-    a.C = workspace;  // unused by this epilogue
+    a.C = probs; a.ldc = ld_probs; a.store_cols = (int)ld_probs; a.out_dtype = dtype;      // NULL: nothing but the partials is stored
+    if (probs && dtype == CAPDEC_BF16) a.fast_epi = 8;
     a.labels = labels; a.ce_B = B; a.ce_L = L;
     a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np;
     hipStream_t st = (hipStream_t)stream;
@@ -1264,7 +1400,7 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     }
     GemmArgs a;
     fill_head_args(a, h, W, bias, M, V, d, ldh, ldw);
-    a.C = workspace;
+    a.C = nullptr;
     a.ce_B = 1; a.ce_L = 1;
     a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np; a.want_sec = margin != nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -1273,6 +1409,38 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
                        (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_logits_ce_bwd_from_probs(void* probs_dl, int dtype, long M, int V, long ld,
+                                               const int64_t* labels, int B, int L, const float* lse, float gscale,
+                                               const void* fwd_workspace, long fwd_workspace_bytes,
+                                               float* dbias, void* workspace, long workspace_bytes, void* stream) {
+    CAPDEC_CHECK(probs_dl && labels && lse, "logits_ce_bwd_from_probs: null pointer");
+    CAPDEC_CHECK(dtype == CAPDEC_BF16 || dtype == CAPDEC_F32, "logits_ce_bwd_from_probs: bad dtype");
+    CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_from_probs: M (%ld) must equal B*L", M);
+    CAPDEC_CHECK(ld >= V && (ld % 8) == 0 && ld <= (long)((V + BN - 1) / BN) * BN && aligned16(probs_dl),
+                 "logits_ce_bwd_from_probs: ld (%ld) must be a multiple of 8 in [V, roundup128(V)]", ld);
+    CeWs ws;
+    if (!carve_ce_ws((void*)fwd_workspace, fwd_workspace_bytes, M, V, ws)) {
+        capdec_set_error("logits_ce_bwd_from_probs: forward workspace too small (%ld < %ld)", fwd_workspace_bytes, capdec_logits_ce_workspace(M, V));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    if (dbias && (!workspace || workspace_bytes < capdec_logits_ce_bwd_workspace(M, V))) {
+        capdec_set_error("logits_ce_bwd_from_probs: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_bwd_workspace(M, V));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    const long ldp = (long)((V + BN - 1) / BN) * BN;
+    dim3 grid((unsigned)((ld + 255) / 256), (unsigned)((M + 63) / 64)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = dbias ? (float*)workspace : nullptr;
+    if (dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL(ce_grad_from_probs_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)probs_dl, ld, M, ws.part4, ws.np, lse, labels, B, L, gscale, part, ldp);
+    else
+        hipLaunchKernelGGL(ce_grad_from_probs_kernel<float>, grid, block, 0, st, (float*)probs_dl, ld, M, ws.part4, ws.np, lse, labels, B, L, gscale, part, ldp);
+    if (dbias)
+        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((V + 63) / 64), dim3(1024), 0, st, (const float*)part, (int)((M + 63) / 64), ldp, V, dbias);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

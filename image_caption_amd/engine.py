@@ -54,6 +54,7 @@ class EngineOptions:
     vocab_slab: int = 0                           # vocabulary columns per backward slab; 0: as wide as dl_budget_bytes allows
     dl_budget_bytes: int = 2 << 30                # cap on the d(logits) slab buffer (the whole vocabulary fits at batch 256)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
+    keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     dropout_seed: int = 42
 
@@ -369,11 +370,9 @@ class DecoderEngine:
         amax = self.buf("ce_argmax", (Mh,), torch.int32, dev)
         loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         correct = torch.empty(1, dtype=torch.int32, device=dev)
-        with self._span("logits_ce_fwd"):
-            ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws)
-        if not want_grads:
-            return loss_sum, correct, Mh
-        # ---- head backward, one vocabulary slab at a time: logits are never materialised
+        # ---- head backward works on d(logits) slabs [Mh, slab] in the compute dtype.  When the whole
+        # vocabulary fits the budget there is one slab, and the forward can leave the softmax numerators in
+        # it (f32 logits are never stored); otherwise the logits are recomputed slab by slab.
         gscale = grad_scale / Mh
         Vpad = (V + 127) // 128 * 128
         slab = self.opt.vocab_slab
@@ -382,7 +381,13 @@ class DecoderEngine:
             slab = max(1024, self.opt.dl_budget_bytes // (Mh * (2 if cdt == torch.bfloat16 else 4)) // 128 * 128)
         slab = min((slab + 127) // 128 * 128, Vpad)
         self.last_slab = slab
-        dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev)
+        from_probs = want_grads and slab >= Vpad and self.opt.keep_softmax_numerators
+        self.last_from_probs = from_probs
+        dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev) if want_grads else None
+        with self._span("logits_ce_fwd"):
+            ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, probs=dl if from_probs else None)
+        if not want_grads:
+            return loss_sum, correct, Mh
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
         bws = self.buf("ce_bwd_ws", (ops.logits_ce_bwd_workspace(Mh, slab),), torch.uint8, dev)
@@ -392,8 +397,12 @@ class DecoderEngine:
             nv = min(slab, V - v0)
             ld = (nv + 127) // 128 * 128
             dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)
-            with self._span("logits_ce_bwd_slab"):
-                ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
+            if from_probs:
+                with self._span("ce_grad_from_probs"):
+                    ops.logits_ce_bwd_from_probs(dls, V, labels, B, L, lse, gscale, ws, gb, bws)
+            else:
+                with self._span("logits_ce_bwd_slab"):
+                    ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
             # the weight gradient first: nothing downstream waits for it but its all-reduce
             with self._span("head_wgrad_slab"):
                 ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)

@@ -186,14 +186,28 @@ def logits_ce_workspace(M, V) -> int:
     return _lib.load().capdec_logits_ce_workspace(M, V)
 
 
-def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace):
-    require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace)
+def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs=None):
+    """probs (optional, [M, ld] of h's dtype): receives the softmax numerators for logits_ce_bwd_from_probs."""
+    require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace, probs)
     M, d = h.shape
     V = W.shape[0]
     assert labels.dtype == torch.int64 and labels.is_contiguous()
+    assert probs is None or (probs.dtype == h.dtype and probs.shape[0] == M)
     check(_lib.load().capdec_logits_ce_fwd(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
-                                           ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct), ptr(workspace),
+                                           ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct),
+                                           ptr(probs), _ld(probs) if probs is not None else 0, ptr(workspace),
                                            workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
+
+
+def logits_ce_bwd_from_probs(probs_dl, V, labels, B, L, lse, gscale, fwd_workspace, dbias=None, workspace=None):
+    """In place: softmax numerators -> (softmax - onehot) * gscale; dbias (optional) overwritten."""
+    require_cuda(probs_dl, labels, lse, fwd_workspace, dbias, workspace)
+    M = probs_dl.shape[0]
+    wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    check(_lib.load().capdec_logits_ce_bwd_from_probs(ptr(probs_dl), dtype_code(probs_dl), M, V, _ld(probs_dl), ptr(labels), B, L,
+                                                      ptr(lse), gscale, ptr(fwd_workspace),
+                                                      fwd_workspace.numel() * fwd_workspace.element_size(),
+                                                      ptr(dbias), ptr(workspace), wsb, _st()), "capdec_logits_ce_bwd_from_probs")
 
 
 def logits_ce_bwd_workspace(M, nv) -> int:

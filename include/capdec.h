@@ -176,15 +176,32 @@ int capdec_attn_decode(const void* q, const void* kv_cache, void* o, int dtype,
  * decoder.py:182-183, without materialising logits.
  * h [M,d] (M = L*B scored rows, row = l*B + b), W [V,d], bias [V] f32,
  * labels [B,L] int64.  Outputs: lse [M], argmax [M] int32, loss_sum[0] (sum of
- * per-row losses), correct[0] (int32).  workspace: capdec_logits_ce_workspace bytes. */
+ * per-row losses), correct[0] (int32).  workspace: capdec_logits_ce_workspace bytes.
+ * probs (optional, [M, ld_probs] of `dtype`, ld_probs a multiple of 8 in [V, roundup128(V)]):
+ * receives the softmax numerators exp(z - max of the column's 64-wide slot) (columns V..ld_probs-1
+ * zero); together with the workspace's per-slot maxima they let capdec_logits_ce_bwd_from_probs
+ * form d(logits) without a second product over the vocabulary. */
 long capdec_logits_ce_workspace(long M, int V);
 int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
                          long M, int V, int d, long ldh, long ldw,
                          const int64_t* labels, int B, int L,
                          float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                         void* probs, long ld_probs,
                          void* workspace, long workspace_bytes, void* stream);
 
-/* Backward of the mean loss w.r.t. logits, one vocabulary slab [v0, v0+nv):
+/* Backward of the mean loss w.r.t. logits (autograd of decoder.py:140,180,189) from what the
+ * forward kept: probs_dl [M, ld] holds the numerators on entry and
+ *   dl[m,n] = (softmax(z)[m,n] - [n == label[m]]) * gscale
+ * on return (in place, same dtype).  fwd_workspace is the forward's workspace, untouched since;
+ * dbias [V] (optional) is OVERWRITTEN with the column sums, through `workspace` of
+ * capdec_logits_ce_bwd_workspace(M, V) bytes. */
+int capdec_logits_ce_bwd_from_probs(void* probs_dl, int dtype, long M, int V, long ld,
+                                    const int64_t* labels, int B, int L, const float* lse, float gscale,
+                                    const void* fwd_workspace, long fwd_workspace_bytes,
+                                    float* dbias, void* workspace, long workspace_bytes, void* stream);
+
+/* The same gradient by RECOMPUTING the logits (for batches whose d(logits) does not fit in one
+ * buffer), one vocabulary slab [v0, v0+nv):
  * dl[m, n-v0] = (exp(z[m,n] - lse[m]) - [n == label[m]]) * gscale, written to
  * dl [M, ld_dl] of `dtype` (columns nv..ld_dl-1 zero-filled); dbias[v0 .. v0+nv) is
  * OVERWRITTEN with the column sums (fixed-order reduction through `workspace` of

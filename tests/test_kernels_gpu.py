@@ -126,6 +126,40 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     close(dbias, ref_dl.sum(0), 1e-2, "dbias")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("B_,L,V,d", [(5, 8, 1111, 64), (16, 32, 50260, 768), (3, 8, 503, 64)])
+def test_logits_ce_backward_from_kept_numerators(dtype, tol, B_, L, V, d):
+    """Forward keeps exp(z - slot max); the backward turns it into (softmax - onehot)/M in place,
+    and must agree with the recomputing backward and with torch."""
+    M = B_ * L
+    h = rnd(M, d, dtype=dtype, seed=61)
+    w = rnd(V, d, dtype=dtype, scale=0.3 if d == 64 else 0.05, seed=62)
+    b = rnd(V, seed=63)
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(64)).to(DEV)
+    z = h.float() @ w.float().t() + b
+    lab_rows = labels.t().reshape(-1)
+    ref_dl = (torch.softmax(z, 1) - torch.nn.functional.one_hot(lab_rows, V)) / M
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    lse, amax = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=dtype)
+    ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, probs=dl)
+    close(lse, torch.logsumexp(z, 1), 2e-3 if dtype == torch.bfloat16 else 1e-5, "lse")
+    # numerators in [0, 1] (fma rounding may exceed 1 by an ulp or two), every element written (no NaN left)
+    assert float(dl.float().min()) >= 0.0 and float(dl.float().max()) <= 1.0 + 1e-5
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+    dbias = torch.full((V,), float("nan"), device=DEV)
+    bws = torch.empty(ops.logits_ce_bwd_workspace(M, V), dtype=torch.uint8, device=DEV)
+    ops.logits_ce_bwd_from_probs(dl, V, labels, B_, L, lse, 1.0 / M, ws, dbias, bws)
+    close(dl[:, :V], ref_dl, tol, "dl from kept numerators")
+    close(dbias, ref_dl.sum(0), tol, "dbias")
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+    dl2 = torch.empty(M, Vp, device=DEV, dtype=dtype)
+    ops.logits_ce_bwd_slab(h, w, b, labels, B_, L, lse, 1.0 / M, 0, V, dl2, None, None)
+    close(dl[:, :V], dl2[:, :V], tol, "kept numerators vs recomputation")
+
+
 @pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gemm_split_k(gemm_mode, mode, M, N, K, out):

@@ -56,13 +56,13 @@ def check_grads(model, ref_grads, dtype):
 
 # ---------------------------------------------------------------------------- golden: tiny, full tensors
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("slab", [0, 128])          # whole vocabulary at once / 4 slabs with a ragged last one
-def test_tiny_golden_logits_loss_grads(dtype, slab):
+@pytest.mark.parametrize("slab,keep", [(0, True), (0, False), (128, True)])   # kept numerators / recomputed / 4 ragged slabs
+def test_tiny_golden_logits_loss_grads(dtype, slab, keep):
     g = golden("tiny.npz")
     sh = TINY
     sd = helpers.make_state_dict(sh, seed=101)
     img, sos, cap, labels = helpers.make_embeddings(sh, seed=202)
-    model = make_model(sh, sd, dtype, vocab_slab=slab)
+    model = make_model(sh, sd, dtype, vocab_slab=slab, keep_softmax_numerators=keep)
     model.train()
     x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
     # (1) the reference's forward: logits for all rows
@@ -86,7 +86,7 @@ def test_tiny_golden_logits_loss_grads(dtype, slab):
     check_grads(model, ref_grads, dtype)
 
 
-@pytest.mark.parametrize("dtype,slab", [(F32, 0), (BF16, 0), (BF16, 8192)])
+@pytest.mark.parametrize("dtype,slab", [(F32, 0), (BF16, 0), (BF16, 8192)])    # slab 8192: the recomputing backward
 def test_default_b8_golden(dtype, slab):
     g = golden("default_b8.npz")
     sh = DEFAULT_B8
