@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--all-rows", action="store_true", help="run every row through the last block (no scored-rows-only skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-greedy", action="store_true")
+    ap.add_argument("--greedy-only", action="store_true", help="skip the training benchmark (profiling of the decoding path)")
     ap.add_argument("--greedy-images", type=int, default=4096)
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--vocab-slab", type=int, default=0, help="vocabulary columns per backward slab (0: engine default)")
@@ -142,6 +143,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.greedy_only:
+        print(json.dumps({"greedy": greedy_bench(model, dev, args)}), flush=True)
+        return
     for _ in range(args.warmup):
         trainer.step(inputs, labels)
     timer = KernelTimer()
@@ -240,10 +244,34 @@ def greedy_bench(model, dev, args):
         ids = model.generate(img, sos, emb, max_len=32)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # roofline of the two kernels that dominate decoding, from one more (untimed) run with event brackets
+    from image_caption_amd.engine import KernelTimer
+    timer = KernelTimer()
+    model.engine.timer = timer
+    model.generate(img, sos, emb, max_len=32)
+    model.engine.timer = None
+    spans = timer.summary()
+    esz = 2 if args.dtype == "bf16" else 4
+    S0 = args.patches + 1
+    roof = {}
+    if "attn_decode" in spans:
+        cnt, ms = spans["attn_decode"]
+        steps = cnt // max(1, args.n_blocks)
+        # every step reads the K and V rows written so far: lengths S0+1 .. S0+steps
+        nbytes = sum(n * 768 * 2 * (S0 + 1 + t) * esz for t in range(steps)) * args.n_blocks
+        roof["attn_decode_kernel"] = {"bound": "hbm", "launches": cnt, "ms_per_launch": round(ms, 4),
+                                      "achieved": round(nbytes / (ms * cnt * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(nbytes / (ms * cnt * 1e-3) / 8e12, 3)}
+    if "logits_argmax" in spans:
+        cnt, ms = spans["logits_argmax"]
+        tf = 2.0 * n * 768 * 50260 / (ms * 1e-3) / 1e12
+        roof["logits_argmax (gemm_bf16_dma_kernel<false,false,1,2,8,3>)"] = {
+            "bound": "mfma", "launches": cnt, "ms_per_launch": round(ms, 4), "achieved": round(tf, 1),
+            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
     model.train()
     return {"metric": "greedy captions/sec", "value": round(n / dt, 1), "unit": "captions/s", "images": n, "max_len": 32,
             "ms_per_batch": round(dt * 1e3, 2), "kv_cache": True, "dtype": args.dtype,
-            "distinct_tokens": int(ids.unique().numel())}
+            "distinct_tokens": int(ids.unique().numel()), "roofline": roof}
 
 
 if __name__ == "__main__":

@@ -634,7 +634,8 @@ class DecoderEngine:
         xo = [self.buf(f"gen_xo{j}", (B, d), torch.float32, dev) for j in range(2)]
         for t in range(max_len):
             ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
-            ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg, ws)
+            with self._span("logits_argmax"):
+                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg, ws)
             if return_margins:
                 margins[:, t].copy_(mg)
             ops.greedy_update(ids, done, out, t, eos_id, pad_id)
@@ -648,7 +649,8 @@ class DecoderEngine:
                 ops.ln_fwd(xcur, w["norm1.weight"], w["norm1.bias"], hs)
                 ops.gemm(hs, w["self_attn.in_proj_weight"], qs, bias=w["self_attn.in_proj_bias"], col_scale=scale, col_scale_n=d,
                          kv_cache=caches[i], kv_geom=(d, d, B, H, hd, smax, s_new))
-                ops.attn_decode(qs, caches[i], os_, B, H, hd, smax, s_new + 1)
+                with self._span("attn_decode"):
+                    ops.attn_decode(qs, caches[i], os_, B, H, hd, smax, s_new + 1)
                 ops.gemm(os_, w["self_attn.out_proj.weight"], xm, bias=w["self_attn.out_proj.bias"], residual=xcur)
                 ops.ln_fwd(xm, w["norm2.weight"], w["norm2.bias"], h2s)
                 ops.gemm(h2s, w["linear1.weight"], a1s, bias=w["linear1.bias"], act=_ACTS[self.opt.activation])

@@ -88,6 +88,17 @@ def vocabulary_cases():
     bws = torch.empty(ops.logits_ce_bwd_workspace(Mt, slab), dtype=torch.uint8, device=DEV)
     stamp_call("CE bwd slab 8192x8192x768", lambda: ops.logits_ce_bwd_slab(x, w, bias, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws),
                (Mt // 128) * (slab // 128), d // 32)
+    Vp = (V + 127) // 128 * 128
+    dlw = torch.zeros(Mt, Vp, device=DEV, dtype=torch.bfloat16)
+    dlw[:, :V] = (torch.randn(Mt, V, device=DEV, generator=g) * 1e-3).to(torch.bfloat16)
+    dWw = torch.empty(V, d, device=DEV)
+    stamp_call("head wgrad 50260x768x8192 (A,B kmajor)", lambda: ops.gemm(dlw, x, dWw, M=V, N=d, K=Mt, a_kmajor=True, b_kmajor=True),
+               ((V + 127) // 128) * 6, Mt // 32)
+    wp = torch.zeros(Vp, d, device=DEV, dtype=torch.bfloat16)
+    wp[:V] = w
+    dHh = torch.empty(Mt, d, device=DEV)
+    stamp_call("head dgrad 8192x768x50304 (B kmajor, no split)", lambda: ops.gemm(dlw, wp, dHh, M=Mt, N=d, K=Vp, b_kmajor=True),
+               (Mt // 128) * 6, Vp // 32)
     dW = torch.empty(slab, d, device=DEV)
     stamp_call("slab wgrad 8192x768x8192 (A,B kmajor)", lambda: ops.gemm(dl, x, dW, a_kmajor=True, b_kmajor=True), (slab // 128) * 6, slab // 64)
 
