@@ -43,7 +43,7 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
 // ------------------------------------------------------------------ LayerNorm forward (+ prefix join)
 // src row for output row r = s*B + b: patches, then the sos slot, then the caption
 template <typename TIN, typename TOUT, bool CONCAT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* sos, const TIN* cap, const float* xin,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs, long img_ss, const TIN* sos, const TIN* cap, const float* xin,
                                                       const float* pos, const float* gamma, const float* beta, float eps,
                                                       long M, int B, int P, int L, int d,
                                                       float* xout, long x_row0, TOUT* y, float* mean, float* rstd) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* 
         if constexpr (CONCAT) {
             s = r / B;
             const long b = r - s * B;
-            src = s < P ? img + (b * P + s) * d : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
+            src = s < P ? img + b * img_bs + s * img_ss : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
         }
 #pragma unroll
         for (int i = 0; i < LN_VEC; ++i) {
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, const TIN* 
 // joined, so the joined rows need not be kept.  dx_out == NULL: only the affine gradients are wanted
 // (the first block's input is data), which drops the two row reductions and the row store.
 template <typename TDY, typename TIN, bool CONCAT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const TIN* img, const TIN* sos, const TIN* cap,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const TIN* img, long img_bs, long img_ss,
+                                                      const TIN* sos, const TIN* cap,
                                                       const float* pos, int B, int P, int L, const float* gamma,
                                                       const float* mean, const float* rstd, long M, int d,
                                                       const float* dx_in, float* dx_out, float* partial) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
         if constexpr (CONCAT) {
             sq = r / B;
             const long b = r - sq * B;
-            src = sq < P ? img + (b * P + sq) * d : (sq == P ? sos + b * d : cap + (b * L + (sq - P - 1)) * d);
+            src = sq < P ? img + b * img_bs + sq * img_ss : (sq == P ? sos + b * d : cap + (b * L + (sq - P - 1)) * d);
         }
         f32x4 g[LN_VEC], xh[LN_VEC];
         float c1 = 0.f, c2 = 0.f;
@@ -374,12 +375,12 @@ extern "C" int capdec_dropout_mask(capdec_dropout d, long n, float* out, void* s
 }
 
 template <typename TIN, typename TOUT, bool CONCAT>
-static void launch_ln_fwd(const void* img, const void* sos, const void* cap, const float* xin, const float* pos,
+static void launch_ln_fwd(const void* img, long img_bs, long img_ss, const void* sos, const void* cap, const float* xin, const float* pos,
                           const float* gamma, const float* beta, float eps, long M, int B, int P, int L, int d,
                           float* xout, long x_row0, void* y, float* mean, float* rstd, hipStream_t st) {
     const long nblk = (M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048;       // 8 workgroups per CU, each wave walks several rows
     hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)nblk), dim3(256), 0, st,
-                       (const TIN*)img, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
+                       (const TIN*)img, img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
                        xout, x_row0, (TOUT*)y, mean, rstd);
 }
 
@@ -395,10 +396,33 @@ extern "C" int capdec_concat_ln_fwd(const void* img, const void* sos, const void
     const long M = (long)(P + 1 + L) * B;
     hipStream_t st = (hipStream_t)stream;
     const bool ib = in_dtype == CAPDEC_BF16, ob = y_dtype == CAPDEC_BF16;
-    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
-    else if (ib) launch_ln_fwd<bf16_t, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
-    else if (ob) launch_ln_fwd<float, bf16_t, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
-    else launch_ln_fwd<float, float, true>(img, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(img, (long)P * d, (long)d, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else if (ib) launch_ln_fwd<bf16_t, float, true>(img, (long)P * d, (long)d, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else if (ob) launch_ln_fwd<float, bf16_t, true>(img, (long)P * d, (long)d, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, true>(img, (long)P * d, (long)d, sos, cap, nullptr, pos, gamma, beta, eps, M, B, P, L, d, x, x_row0, y, mean, rstd, st);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_seqfirst_ln_fwd(const void* tgt, int in_dtype, long seq_stride, long batch_stride,
+                                      const float* pos, const float* gamma, const float* beta, float eps,
+                                      int S, int B, int d,
+                                      float* x, long x_row0, void* y, int y_dtype, float* mean, float* rstd, void* stream) {
+    CAPDEC_CHECK(tgt && x_row0 >= 0, "seqfirst_ln_fwd: bad arguments");
+    CAPDEC_CHECK(S > 0 && B > 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "seqfirst_ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    const int align = in_dtype == CAPDEC_BF16 ? 8 : 4;
+    CAPDEC_CHECK((seq_stride % align) == 0 && (batch_stride % align) == 0 && aligned16(tgt),
+                 "seqfirst_ln_fwd: strides must keep rows 16-byte aligned (seq %ld, batch %ld)", seq_stride, batch_stride);
+    CAPDEC_CHECK(x || y, "seqfirst_ln_fwd: nothing to write");
+    CAPDEC_CHECK(!y || (gamma && beta), "seqfirst_ln_fwd: LayerNorm output needs gamma/beta");
+    const long M = (long)S * B;
+    hipStream_t st = (hipStream_t)stream;
+    const bool ib = in_dtype == CAPDEC_BF16, ob = y_dtype == CAPDEC_BF16;
+    // one segment of S rows per sample: the "patch" segment of the join with its own strides
+    if (ib && ob) launch_ln_fwd<bf16_t, bf16_t, true>(tgt, batch_stride, seq_stride, tgt, tgt, nullptr, pos, gamma, beta, eps, M, B, S, 0, d, x, x_row0, y, mean, rstd, st);
+    else if (ib) launch_ln_fwd<bf16_t, float, true>(tgt, batch_stride, seq_stride, tgt, tgt, nullptr, pos, gamma, beta, eps, M, B, S, 0, d, x, x_row0, y, mean, rstd, st);
+    else if (ob) launch_ln_fwd<float, bf16_t, true>(tgt, batch_stride, seq_stride, tgt, tgt, nullptr, pos, gamma, beta, eps, M, B, S, 0, d, x, x_row0, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, true>(tgt, batch_stride, seq_stride, tgt, tgt, nullptr, pos, gamma, beta, eps, M, B, S, 0, d, x, x_row0, y, mean, rstd, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -409,8 +433,8 @@ extern "C" int capdec_ln_fwd(const float* x, const float* gamma, const float* be
     CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_fwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
     if (M <= 0) return CAPDEC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (y_dtype == CAPDEC_BF16) launch_ln_fwd<float, bf16_t, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
-    else launch_ln_fwd<float, float, false>(nullptr, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
+    if (y_dtype == CAPDEC_BF16) launch_ln_fwd<float, bf16_t, false>(nullptr, 0, 0, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
+    else launch_ln_fwd<float, float, false>(nullptr, 0, 0, nullptr, nullptr, x, nullptr, gamma, beta, eps, M, 1, 0, 0, d, nullptr, 0, y, mean, rstd, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -428,29 +452,30 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
     const int nb = ln_bwd_blocks(M);
     const float* nf = nullptr;
     if (dy_dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float, false>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, nf, nf, nf, nf, 1, 0, 0,
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float, false>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0,
                            gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float, false>), dim3(nb), dim3(256), 0, st, (const float*)dy, x, nf, nf, nf, nf, 1, 0, 0,
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float, false>), dim3(nb), dim3(256), 0, st, (const float*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0,
                            gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
 
-extern "C" int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const void* img, const void* sos, const void* cap, int in_dtype,
-                                           const float* pos, const float* gamma, const float* mean, const float* rstd,
-                                           int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, void* stream) {
-    CAPDEC_CHECK(dy && img && sos && cap && gamma && mean && rstd && dgamma && dbeta && partial, "concat_ln_bwd_affine: null pointer");
-    CAPDEC_CHECK(B > 0 && P >= 0 && L >= 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "concat_ln_bwd_affine: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
-    const long M = (long)(P + 1 + L) * B;
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+// affine gradients of a LayerNorm whose input rows are re-read from their sources: a first segment of P rows
+// per sample with strides (img_bs, img_ss), then the sos row, then L caption rows
+int ln_bwd_affine_from_sources(const void* dy, int dy_dtype, const void* img, long img_bs, long img_ss, const void* sos, const void* cap,
+                               int in_dtype, const float* pos, const float* gamma, const float* mean, const float* rstd,
+                               int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, hipStream_t st) {
+    const long M = (long)(P + (L >= 0 ? 1 + L : 0)) * B;
     const int nb = ln_bwd_blocks(M);
     const float* nf = nullptr;
     float* nd = nullptr;
+    const int Lk = L >= 0 ? L : 0;
 #define CAPDEC_LNB(TDY, TIN)                                                                                             \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TIN, true>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, nf, (const TIN*)img,   \
-                       (const TIN*)sos, (const TIN*)cap, pos, B, P, L, gamma, mean, rstd, M, d, nf, nd, (float*)partial)
+                       img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, pos, B, P, Lk, gamma, mean, rstd, M, d, nf, nd, (float*)partial)
     const bool db = dy_dtype == CAPDEC_BF16, ib = in_dtype == CAPDEC_BF16;
     if (db && ib) CAPDEC_LNB(bf16_t, bf16_t);
     else if (db) CAPDEC_LNB(bf16_t, float);
@@ -460,6 +485,28 @@ extern "C" int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const v
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
+}
+}  // namespace
+
+extern "C" int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const void* img, const void* sos, const void* cap, int in_dtype,
+                                           const float* pos, const float* gamma, const float* mean, const float* rstd,
+                                           int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, void* stream) {
+    CAPDEC_CHECK(dy && img && sos && cap && gamma && mean && rstd && dgamma && dbeta && partial, "concat_ln_bwd_affine: null pointer");
+    CAPDEC_CHECK(B > 0 && P >= 0 && L >= 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "concat_ln_bwd_affine: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    return ln_bwd_affine_from_sources(dy, dy_dtype, img, (long)P * d, (long)d, sos, cap, in_dtype, pos, gamma, mean, rstd, B, P, L, d,
+                                      dgamma, dbeta, partial, (hipStream_t)stream);
+}
+
+extern "C" int capdec_seqfirst_ln_bwd_affine(const void* dy, int dy_dtype, const void* tgt, int in_dtype, long seq_stride, long batch_stride,
+                                             const float* pos, const float* gamma, const float* mean, const float* rstd,
+                                             int S, int B, int d, float* dgamma, float* dbeta, void* partial, void* stream) {
+    CAPDEC_CHECK(dy && tgt && gamma && mean && rstd && dgamma && dbeta && partial, "seqfirst_ln_bwd_affine: null pointer");
+    CAPDEC_CHECK(S > 0 && B > 0 && d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "seqfirst_ln_bwd_affine: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    const int align = in_dtype == CAPDEC_BF16 ? 8 : 4;
+    CAPDEC_CHECK((seq_stride % align) == 0 && (batch_stride % align) == 0 && aligned16(tgt),
+                 "seqfirst_ln_bwd_affine: strides must keep rows 16-byte aligned (seq %ld, batch %ld)", seq_stride, batch_stride);
+    return ln_bwd_affine_from_sources(dy, dy_dtype, tgt, batch_stride, seq_stride, tgt, tgt, in_dtype, pos, gamma, mean, rstd, B, S, -1, d,
+                                      dgamma, dbeta, partial, (hipStream_t)stream);
 }
 
 extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {

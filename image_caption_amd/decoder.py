@@ -160,17 +160,20 @@ class TransformerDecoder(nn.Module):
 
     @torch.no_grad()
     def generate(self, img, sos_slot, token_embedding, *, max_len=None, sos_id=None, eos_id=None, pad_id=None, pos=None,
-                 return_margins=False):
+                 return_margins=False, stop_check_every=0):
         """Greedy captions [B,max_len] for image prefixes img [B,P,d].  The special ids
         default to the reference tokenizer's add order (img_text_concat.py:22-26):
-        <sos>=V-3, <eos>=V-2, <pad>=V-1."""
+        <sos>=V-3, <eos>=V-2, <pad>=V-1.  A sequence that has produced <eos> emits <pad> from
+        then on; with stop_check_every=k the loop also ends once every sequence has (checked
+        every k tokens, one host synchronisation each)."""
         V = self.vocab_size
         max_len = config.max_caption_length if max_len is None else max_len
         sos_id = V - 3 if sos_id is None else sos_id
         eos_id = V - 2 if eos_id is None else eos_id
         pad_id = V - 1 if pad_id is None else pad_id
         return self.engine.generate(self._weights(), img, sos_slot, token_embedding, max_len=max_len, sos_id=sos_id,
-                                    eos_id=eos_id, pad_id=pad_id, pos=pos, return_margins=return_margins)
+                                    eos_id=eos_id, pad_id=pad_id, pos=pos, return_margins=return_margins,
+                                    stop_check_every=stop_check_every)
 
     def _source(self, inputs):
         if isinstance(inputs, (tuple, list)):
@@ -301,9 +304,7 @@ def train_decoder(processed_data, config=config, *, options: Optional[EngineOpti
     start = time.time()
     total = processed_data["decoder_inputs"].size(1)
     train_size = int(config.train_fraction * total)
-    splits = []
-    for name, sl in (("train", slice(0, train_size)), ("test", slice(train_size, total))):
-        splits.append((name, processed_data["decoder_inputs"][:, sl, :], processed_data["caption_labels"][sl, :]))
+    bounds = (("train", 0, train_size), ("test", train_size, total))
     log(f"\nSplit data into:\n- Training: {train_size} examples\n- Testing: {total - train_size} examples")
     device = torch.device(config.device)
     if device.type != "cuda":
@@ -313,20 +314,20 @@ def train_decoder(processed_data, config=config, *, options: Optional[EngineOpti
                                options=options).to(device)
     trainer = CaptionTrainer(model, lr=config.learning_rate, weight_decay=config.weight_decay)
     L = config.max_caption_length
+    if processed_data["caption_labels"].size(1) != L:
+        raise ValueError(f"labels have {processed_data['caption_labels'].size(1)} columns, config.max_caption_length is {L}")
+    # each split lives on the device when it fits (its batches are then strided views, decoder.py:163),
+    # otherwise it is streamed from pinned host memory ahead of the compute stream
+    from .dataset import BatchSource
+    splits = [(name, BatchSource(processed_data, config.batch_size, device, lo=lo, hi=hi)) for name, lo, hi in bounds]
     history = []
     for epoch in range(config.num_epochs):
         model.train()
-        for split_name, xs, ys in splits:
-            n = xs.size(1)
+        for split_name, source in splits:
             loss_acc = torch.zeros(1, device=device)
             correct_acc = torch.zeros(1, dtype=torch.int64, device=device)
             batches = tokens = 0
-            for i in range(0, n, config.batch_size):
-                j = min(i + config.batch_size, n)
-                x = xs[:, i:j, :].to(device, non_blocking=True).contiguous()
-                y = ys[i:j, :].to(device, non_blocking=True).contiguous()
-                if y.size(1) != L:
-                    raise ValueError(f"labels have {y.size(1)} columns, config.max_caption_length is {L}")
+            for x, y in source:
                 loss_sum, correct, rows = trainer.step(x, y)
                 loss_acc += loss_sum / rows
                 correct_acc += correct

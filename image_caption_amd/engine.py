@@ -333,7 +333,15 @@ class DecoderEngine:
                     x0 = self.buf("x0", (M, d), torch.float32, dev)
                     ops.concat_ln_fwd(img, sos, cap, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0,
                                       x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
-                    concat_src = (img, sos, cap, pos)
+                    concat_src = ("concat", img, sos, cap, pos)
+                elif (tgt.dtype in (torch.float32, torch.bfloat16) and tgt.stride(2) == 1 and tgt.data_ptr() % 16 == 0
+                      and all(st % (4 if tgt.dtype == torch.float32 else 8) == 0 for st in tgt.stride()[:2])
+                      and (pos is not None or not keep_joined or tgt.dtype != torch.float32 or not tgt.is_contiguous())):
+                    # a strided seq-first slice (dataset[:, i:j, :]) is normalised where it lies: no contiguous copy
+                    x0 = self.buf("x0", (M, d), torch.float32, dev)
+                    ops.seqfirst_ln_fwd(tgt, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0,
+                                        x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
+                    concat_src = ("seqfirst", tgt, pos)
                 else:
                     x0 = tgt.reshape(M, d)
                     if x0.dtype != torch.float32 or not x0.is_contiguous():
@@ -503,9 +511,12 @@ class DecoderEngine:
                 ops.gemm(dqkv[:r0, d:], in_w[d:], dh1[:r0], M=r0, N=d, K=2 * d, b_kmajor=True)
                 ops.gemm(dqkv[r0:], in_w, dh1[r0:], M=Mt, N=d, K=3 * d, b_kmajor=True)
             src = sv.get("concat_src")
-            if src is not None:
-                ops.concat_ln_bwd_affine(dh1, src[0], src[1], src[2], w["norm1.weight"], sv["mean1"], sv["rstd1"],
-                                         G("norm1.weight"), G("norm1.bias"), lnws, pos=src[3])
+            if src is not None and src[0] == "concat":
+                ops.concat_ln_bwd_affine(dh1, src[1], src[2], src[3], w["norm1.weight"], sv["mean1"], sv["rstd1"],
+                                         G("norm1.weight"), G("norm1.bias"), lnws, pos=src[4])
+            elif src is not None:
+                ops.seqfirst_ln_bwd_affine(dh1, src[1], w["norm1.weight"], sv["mean1"], sv["rstd1"],
+                                           G("norm1.weight"), G("norm1.bias"), lnws, pos=src[2])
             else:
                 ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], None, None,
                            G("norm1.weight"), G("norm1.bias"), lnws)
@@ -562,7 +573,7 @@ class DecoderEngine:
     # ------------------------------------------------------------------ KV-cached greedy decoding
     @torch.no_grad()
     def generate(self, W: _Weights, img, sos_slot, emb, *, max_len: int, sos_id: int, eos_id: int, pad_id: int,
-                 pos=None, return_margins: bool = False):
+                 pos=None, return_margins: bool = False, stop_check_every: int = 0):
         """Greedy captions for a batch of image prefixes.  seq0 = [img | sos_slot | E[sos]];
         step t scores the last row, appends E[argmax].  K/V of every row are computed
         once and cached ([B,H,2,S,hd] per block).  Returns ids [B,max_len] int64."""
@@ -640,6 +651,10 @@ class DecoderEngine:
                 margins[:, t].copy_(mg)
             ops.greedy_update(ids, done, out, t, eos_id, pad_id)
             if t + 1 == max_len:
+                break
+            # <eos> early stop: the remaining columns already hold <pad>.  Looking at `done` is a host
+            # synchronisation, so it is only done every stop_check_every steps (0: never).
+            if stop_check_every > 0 and (t + 1) % stop_check_every == 0 and bool(done.all().item()):
                 break
             s_new = S0 + t                                           # index of the appended row
             ops.embed_rows(emb, ids, xs, pos_row=pos[s_new].contiguous() if pos is not None else None)

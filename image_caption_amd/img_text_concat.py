@@ -53,3 +53,27 @@ def process_batch(batch):
         "caption_input_ids": batch["caption_input_ids"],
         "caption_labels": batch["caption_labels"],
     }
+
+
+def captions_from_ids(ids, tokenizer=None, *, eos_id=None, pad_id=None, sos_id=None, vocab_size=50260):
+    """Generated id rows -> per-sample token lists (and text when a tokenizer is given): the step
+    after greedy decoding.  A caption ends before the first <eos>; <pad> and <sos> never belong to
+    it.  Special ids default to the reference tokenizer's add order (img_text_concat.py:22-26).
+    ``tokenizer`` is any object with ``decode(list_of_ids) -> str`` (the reference's GPT-2
+    tokenizer; its assets are not available offline, so none is constructed here)."""
+    sos_id = vocab_size - 3 if sos_id is None else sos_id
+    eos_id = vocab_size - 2 if eos_id is None else eos_id
+    pad_id = vocab_size - 1 if pad_id is None else pad_id
+    rows = ids.tolist() if hasattr(ids, "tolist") else [list(r) for r in ids]
+    out = []
+    for row in rows:
+        toks = []
+        for t in row:
+            if t == eos_id:
+                break
+            if t != pad_id and t != sos_id:
+                toks.append(int(t))
+        out.append(toks)
+    if tokenizer is None:
+        return out
+    return [tokenizer.decode(t) for t in out]

@@ -50,6 +50,31 @@ def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None,
           "capdec_concat_ln_fwd")
 
 
+def _seqfirst_strides(tgt):
+    assert tgt.dim() == 3 and tgt.stride(2) == 1, "seq-first batch must be [S, B, d] with unit stride along d"
+    return tgt.stride(0), tgt.stride(1)
+
+
+def seqfirst_ln_fwd(tgt, gamma, beta, *, pos=None, eps=1e-5, x_out=None, x_row0=0, y_out=None, mean=None, rstd=None):
+    """tgt: [S, B, d] view (any seq / batch strides, e.g. dataset[:, i:j, :] on the device)."""
+    require_cuda(tgt, pos, gamma, beta, x_out, y_out, mean, rstd)
+    S, B, d = tgt.shape
+    ss, bs = _seqfirst_strides(tgt)
+    check(_lib.load().capdec_seqfirst_ln_fwd(ptr(tgt), dtype_code(tgt), ss, bs, ptr(pos), ptr(gamma), ptr(beta), eps, S, B, d,
+                                             ptr(x_out), x_row0, ptr(y_out), dtype_code(y_out) if y_out is not None else F32,
+                                             ptr(mean), ptr(rstd), _st()), "capdec_seqfirst_ln_fwd")
+
+
+def seqfirst_ln_bwd_affine(dy, tgt, gamma, mean, rstd, dgamma, dbeta, partial, pos=None):
+    require_cuda(dy, tgt, pos, gamma, mean, rstd, dgamma, dbeta, partial)
+    S, B, d = tgt.shape
+    ss, bs = _seqfirst_strides(tgt)
+    assert dy.is_contiguous() and dy.shape == (S * B, d)
+    check(_lib.load().capdec_seqfirst_ln_bwd_affine(ptr(dy), dtype_code(dy), ptr(tgt), dtype_code(tgt), ss, bs, ptr(pos), ptr(gamma),
+                                                    ptr(mean), ptr(rstd), S, B, d, ptr(dgamma), ptr(dbeta), ptr(partial), _st()),
+          "capdec_seqfirst_ln_bwd_affine")
+
+
 def ln_fwd(x, gamma, beta, y_out, mean=None, rstd=None, eps=1e-5):
     require_cuda(x, gamma, beta, y_out)
     M, d = x.shape

@@ -67,6 +67,15 @@ int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int 
                          int B, int P, int L, int d,
                          float* x, long x_row0, void* y, int y_dtype, float* mean, float* rstd, void* stream);
 
+/* The same fused step for an already joined, seq-first batch taken as a strided view of the
+ * processed dataset: decoder.py:163 (`split_data['decoder_inputs'][:, i:batch_end, :]`, element
+ * (s, b, j) at tgt[s*seq_stride + b*batch_stride + j]) + decoder.py:53 (norm1), without first
+ * making the slice contiguous.  Outputs as for capdec_concat_ln_fwd with rows r = s*B + b. */
+int capdec_seqfirst_ln_fwd(const void* tgt, int in_dtype, long seq_stride, long batch_stride,
+                           const float* pos, const float* gamma, const float* beta, float eps,
+                           int S, int B, int d,
+                           float* x, long x_row0, void* y, int y_dtype, float* mean, float* rstd, void* stream);
+
 /* decoder.py:53,58 (nn.LayerNorm, eps 1e-5): y = LN(x) for x [M,d] f32. */
 int capdec_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, long M, int d,
                   void* y, int y_dtype, float* mean, float* rstd, void* stream);
@@ -87,6 +96,11 @@ int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
 int capdec_concat_ln_bwd_affine(const void* dy, int dy_dtype, const void* img, const void* sos, const void* cap, int in_dtype,
                                 const float* pos, const float* gamma, const float* mean, const float* rstd,
                                 int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, void* stream);
+
+/* The same for a seq-first strided batch (see capdec_seqfirst_ln_fwd); dy [S*B, d]. */
+int capdec_seqfirst_ln_bwd_affine(const void* dy, int dy_dtype, const void* tgt, int in_dtype, long seq_stride, long batch_stride,
+                                  const float* pos, const float* gamma, const float* mean, const float* rstd,
+                                  int S, int B, int d, float* dgamma, float* dbeta, void* partial, void* stream);
 
 /* ------------------------------------------------------------------ GEMM + fused epilogue
  * C[m,n] = epilogue( sum_k A(m,k) * B(n,k) ).  Replaces every nn.Linear of

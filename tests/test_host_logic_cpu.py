@@ -89,3 +89,17 @@ def test_product_package_never_imports_the_oracle():
             elif isinstance(node, ast.ImportFrom):
                 names = [node.module or ""]
             assert not any(n.split(".")[0] == "oracle" for n in names), f"{fn} imports the oracle"
+
+
+def test_captions_from_ids_cuts_at_eos_and_drops_specials():
+    import torch
+    from image_caption_amd.img_text_concat import captions_from_ids
+    V = 50260
+    ids = torch.tensor([[50257, 11, 12, 50258, 13, 50259], [5, 6, 7, 8, 9, 10], [50258, 1, 2, 3, 4, 5]])
+    assert captions_from_ids(ids) == [[11, 12], [5, 6, 7, 8, 9, 10], []]
+
+    class Tok:
+        def decode(self, t):
+            return " ".join(f"w{i}" for i in t)
+    assert captions_from_ids(ids, Tok(), vocab_size=V) == ["w11 w12", "w5 w6 w7 w8 w9 w10", ""]
+    assert captions_from_ids([[1, 2, 9, 3]], eos_id=9, pad_id=0, sos_id=7) == [[1, 2]]

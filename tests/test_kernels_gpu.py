@@ -443,6 +443,35 @@ def test_logits_ce(dtype, tol, B, L, V, d):
     close(dW, Wr.grad, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dW")
 
 
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+def test_seqfirst_strided_ln_fwd_bwd(in_dtype):
+    """LayerNorm-1 straight off a strided dataset slice [:, i:j, :] (decoder.py:163)."""
+    S, N, d, i, j = 9, 11, 64, 3, 8
+    B = j - i
+    full = rnd(S, N, d, seed=70).to(in_dtype)
+    tgt = full[:, i:j, :]                                   # seq stride N*d, batch stride d, not contiguous
+    assert not tgt.is_contiguous()
+    pos = rnd(S, d, seed=71)
+    gamma, beta = 1 + 0.1 * rnd(d, seed=72), 0.1 * rnd(d, seed=73)
+    xr = (tgt.float() + pos[:, None]).reshape(S * B, d)
+    x = torch.full((S * B, d), float("nan"), device=DEV)
+    y = torch.empty(S * B, d, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(S * B, device=DEV), torch.empty(S * B, device=DEV)
+    ops.seqfirst_ln_fwd(tgt, gamma, beta, pos=pos, x_out=x, x_row0=2 * B, y_out=y, mean=mean, rstd=rstd)
+    assert torch.equal(x[2 * B:], xr[2 * B:]) and bool(torch.isnan(x[:2 * B]).all())
+    close(y, torch.nn.functional.layer_norm(xr, (d,), gamma, beta, 1e-5), 1e-2, "ln of a strided slice")
+    dy = rnd(S * B, d, seed=74).to(torch.bfloat16)
+    ws = torch.empty(ops.ln_bwd_workspace(S * B, d), dtype=torch.uint8, device=DEV)
+    dg, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    ops.seqfirst_ln_bwd_affine(dy, tgt, gamma, mean, rstd, dg, db, ws, pos=pos)
+    dg2, db2 = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    ops.ln_bwd(dy, xr.contiguous(), gamma, mean, rstd, None, None, dg2, db2, ws)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    bad = rnd(S, N, d, seed=75).as_strided((S, B, d), (N * d + 2, d, 1))           # rows no longer 16-byte aligned
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        ops.seqfirst_ln_fwd(bad, gamma, beta, y_out=torch.empty(S * B, d, device=DEV))
+
+
 # ---------------------------------------------------------------------------- element-wise
 def test_elementwise_and_adam():
     M, N = 130, 72

@@ -82,6 +82,9 @@ def vocabulary_cases():
     ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
     stamp_call("logits+CE fwd 8192x50260x768", lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws),
                (Mt // 128) * ((V + 127) // 128), d // 32)
+    probs = torch.empty(Mt, (V + 127) // 128 * 128, device=DEV, dtype=torch.bfloat16)
+    stamp_call("logits+CE fwd keeping the softmax numerators", lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws, probs=probs),
+               (Mt // 128) * ((V + 127) // 128), d // 32)
     slab = 8192
     dl = torch.empty(Mt, slab, device=DEV, dtype=torch.bfloat16)
     dbias = torch.zeros(V, device=DEV)
