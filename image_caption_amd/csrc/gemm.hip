@@ -2,18 +2,20 @@
 //
 //   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
 //
-// bf16 operands: 128x128x64 tiles, 4 waves (2x2), each wave 4x4 MFMA 16x16x32
-// tiles with f32 accumulators.  Operand tiles are fetched with bounds-checked
-// buffer loads (out-of-range reads return 0, which implements every M/N/K tail),
-// staged in LDS with an XOR swizzle, double buffered.  An operand stored
-// reduction-major ([K][rows], the dgrad / wgrad cases) is read back with the
-// hardware transposing LDS read (ds_read_b64_tr_b16), so no transposed copies of
-// weights or activations are ever made.
+// bf16 operands, f32 accumulators, MFMA 16x16x32.  Two main loops share the epilogues:
+//   * an LDS-DMA ring (operand tiles go global -> LDS without staging registers, counted
+//     vmcnt waits): 256x128 tiles with 4 waves of 128x64 where the grid allows it, else
+//     128x128 tiles with 4 waves of 64x64; two workgroups per CU either way;
+//   * a register-staged 128x128x64 loop for ragged K and the small split-K products.
+// Out-of-range reads return 0 through the buffer descriptor, which implements every
+// M/N/K tail.  An operand stored reduction-major ([K][rows], the dgrad / wgrad cases) is
+// read back with the hardware transposing LDS read (ds_read_b64_tr_b16), so no
+// transposed copies of weights or activations are ever made.
 // f32 operands: exact-f32 FMA main loop (validation mode), same epilogues.
 //
-// Every epilogue works on the accumulator tile after it has been staged through
-// LDS, row-major, so global stores / residual reads are 8-16 B per lane and
-// contiguous across 16 lanes.
+// Every epilogue works on the accumulator tile after it has been staged through a
+// wave-private LDS tile, row-major, so global stores are 16 B per lane and contiguous
+// across 8-16 lanes.
 #include "common.h"
 
 namespace {
@@ -331,16 +333,6 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
             if (lane < 16 && e < nvalid) atomicAdd(p.colsum + n + e, s);
         }
     }
-}
-
-struct Top2 { float m1; int a1; float m2; };
-__device__ __forceinline__ void top2_push(Top2& t, float v, int idx) {
-    if (v > t.m1 || (v == t.m1 && idx < t.a1)) { t.m2 = t.m1; t.m1 = v; t.a1 = idx; }
-    else if (v > t.m2) t.m2 = v;
-}
-__device__ __forceinline__ void top2_merge(Top2& t, float m1, int a1, float m2) {
-    if (m1 > t.m1 || (m1 == t.m1 && a1 < t.a1)) { t.m2 = fmaxf(t.m1, m2); t.m1 = m1; t.a1 = a1; }
-    else t.m2 = fmaxf(t.m2, m1);
 }
 
 __device__ __forceinline__ int row_label(const GemmArgs& p, long m) {
@@ -698,16 +690,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ bf16 MFMA kernel, LDS-DMA ring
 // Same tile and epilogues, but operand tiles go global -> LDS directly
-// (buffer_load ... lds, 16 B per lane, no staging registers) into a ring of four
-// 32-deep stages.  Three stages are in flight while one is multiplied; the wait is a
-// COUNTED vmcnt (the two youngest stages stay in flight across the barrier), so a
-// tile's HBM/L2 latency is covered by three MFMA phases.  An LDS-DMA writes
+// (buffer_load ... lds, 16 B per lane, no staging registers) into a ring of NST
+// 32-deep stages.  NST-1 stages are in flight while one is multiplied; the wait is a
+// COUNTED vmcnt (the NST-2 youngest stages stay in flight across the barrier), so a
+// tile's HBM/L2 latency is covered by NST-1 MFMA phases.  An LDS-DMA writes
 // wave-base + 16*lane, i.e. the LDS image is lane-linear per wave instruction;
 // the bank-conflict swizzle is therefore applied to the per-lane SOURCE address and
 // undone by the same XOR on the fragment read.  Needs K % 32 == 0 unless both operands are
 // reduction-major (other K: the register-staged kernel above); M/N tails are out-of-range
 // rows whose results are never stored.
-constexpr int DBK = 32, DSTAGES = 4, DTILE_BYTES = 8192, DSTAGE_BYTES = 2 * DTILE_BYTES;
+constexpr int DBK = 32, DTILE_BYTES = 8192;      // k-depth of a ring stage; bytes of a 128-row (or 128-column) 32-deep operand image
 
 // row-major [128 rows][32 k] bf16, 64-B rows; chunk (0..3) XOR 3*((row>>3)&1): conflict-free ds_read_b128
 __device__ __forceinline__ int dlds_rowmajor(int row, int kc) { return row * 64 + ((kc ^ (((row >> 3) & 1) * 3)) << 4); }
