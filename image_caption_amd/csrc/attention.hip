@@ -558,15 +558,16 @@ __global__ void attn_decode_kernel(const T* q, const T* cache, T* o, int H, int 
     const T* Vc = cache + ((long)bh * 2 + 1) * smax * HD;
     for (int j = tid; j < HD; j += NTH) qs[j] = to_f32<T>(q[(long)bh * HD + j]);
     __syncthreads();
+    // K and V are streamed once per generated token: non-temporal loads keep them from evicting the weights
     for (int key = kk; key < len; key += KPP) {
         const T* src = Kc + (long)key * HD + part * E;
         float a = 0.f;
         if constexpr (sizeof(T) == 2) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+            const bf16x8 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
 #pragma unroll
             for (int e = 0; e < E; ++e) a = fmaf(qs[part * E + e], (float)v[e], a);
         } else {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
 #pragma unroll
             for (int e = 0; e < E; ++e) a = fmaf(qs[part * E + e], v[e], a);
         }
@@ -592,11 +593,11 @@ __global__ void attn_decode_kernel(const T* q, const T* cache, T* o, int H, int 
         const T* src = Vc + (long)key * HD + part * E;
         const float w = sc[key];
         if constexpr (sizeof(T) == 2) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+            const bf16x8 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = fmaf(w, (float)v[e], acc[e]);
         } else {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = fmaf(w, v[e], acc[e]);
         }

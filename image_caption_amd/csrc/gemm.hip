@@ -412,7 +412,9 @@ __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, in
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)a[e]; o[4 + e] = (bf16_t)b[e]; }
-                *reinterpret_cast<bf16x8*>(C + mm * p.ldc + n) = o;
+                // 0.8 GB that is next read after everything in the caches has turned over: stream it past them,
+                // so that it does not evict the W / x panels the main loops of the other tiles are re-reading
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + mm * p.ldc + n));
             } else {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(src);
                 bf16x4 o;
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(256) void ce_grad_from_probs_kernel(T* pd, long ld,
             T* ptr = pd + m * ld + n;
             float v[8];
             if constexpr (sizeof(T) == 2) {
-                const bf16x8 q = *reinterpret_cast<const bf16x8*>(ptr);
+                const bf16x8 q = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(ptr));      // streamed once: keep it out of the caches
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (float)q[e];
             } else {
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(256) void ce_grad_from_probs_kernel(T* pd, long ld,
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                *reinterpret_cast<bf16x8*>(ptr) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(ptr));
             } else {
                 *reinterpret_cast<f32x4*>(ptr) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(ptr + 4) = f32x4{v[4], v[5], v[6], v[7]};

@@ -30,6 +30,17 @@ __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
     const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
+// the same for data that is read once per step (the join's sources): non-temporal, so that it does not
+// displace what the following kernels re-read from the caches
+template <typename T>
+__device__ __forceinline__ f32x4 load4_stream(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load4_stream<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+template <>
+__device__ __forceinline__ f32x4 load4_stream<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 template <typename T>
 __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <>
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < d) {
                 if constexpr (CONCAT) {
-                    v[i] = load4<TIN>(src + c);
+                    v[i] = load4_stream<TIN>(src + c);
                     if (pos) v[i] += *reinterpret_cast<const f32x4*>(pos + s * d + c);
                     if (xo) *reinterpret_cast<f32x4*>(xo + r * d + c) = v[i];
                 } else {
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
                 const f32x4 dyv = load4<TDY>(dy + r * d + c);
                 f32x4 xv;
                 if constexpr (CONCAT) {
-                    xv = load4<TIN>(src + c);
+                    xv = load4_stream<TIN>(src + c);
                     if (pos) xv += *reinterpret_cast<const f32x4*>(pos + sq * d + c);
                 } else {
                     xv = *reinterpret_cast<const f32x4*>(x + r * d + c);
@@ -318,10 +329,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
-            f32x4 wv = *reinterpret_cast<f32x4*>(w + i);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-            f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
-            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+            // one pass over 1.3 GB that nothing re-reads soon: streaming (non-temporal) accesses keep it
+            // from evicting the weights' bf16 shadow and the activations from L2 / the Infinity Cache
+            f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + i));
+            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i));
+            f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float gg = gv[e] * gscale + wd * wv[e];
@@ -329,9 +342,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
                 vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
                 wv[e] -= lr_over_bc1 * (mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps));
             }
-            *reinterpret_cast<f32x4*>(w + i) = wv;
-            *reinterpret_cast<f32x4*>(m + i) = mv;
-            *reinterpret_cast<f32x4*>(v + i) = vv;
+            __builtin_nontemporal_store(wv, reinterpret_cast<f32x4*>(w + i));
+            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + i));
+            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
             if (wb) store4<bf16_t>(wb + i, wv);
         } else {
             for (long j = i; j < n; ++j) {
