@@ -475,7 +475,7 @@ __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, in
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                *reinterpret_cast<bf16x8*>(C + m * p.ldc + n) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + m * p.ldc + n));      // streamed: read back only by the dgrad / wgrad
             } else {
                 bf16x4 o;
 #pragma unroll
