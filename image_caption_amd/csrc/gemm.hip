@@ -1035,9 +1035,10 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ CE finalize kernels
-// Fold the per-slot partials into lse / argmax / margin / row loss.  A block owns 64 rows (one per
-// lane, so every partial read is a contiguous 1 KiB per wave); its 16 waves each fold every 16th slot
-// with an online rescaling of the sum, and wave 0 merges the 16 results in a fixed order (deterministic).
+// Fold the per-slot partials into lse / argmax / margin / row loss.  A block owns 32 rows; thread
+// (row = t & 31, group = t >> 5) folds every 32nd slot of its row with an online rescaling of the sum
+// (the 32 rows of a slot are 512 contiguous bytes), and the first 32 threads merge the 32 groups in a
+// fixed order (deterministic).  32 rows per block puts 256 blocks on the chip at 8192 rows.
 struct RowFold { float m1; int a1; float m2; float s; };
 __device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2, float ps) {
     if (pm > t.m1 || (pm == t.m1 && pa < t.a1)) {
@@ -1048,26 +1049,27 @@ __device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2
         t.m2 = fmaxf(t.m2, pm);
     }
 }
+constexpr int FIN_ROWS = 32, FIN_GROUPS = 32;
 __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, const float* zlabel, const int64_t* labels,
                                                            int ce_B, int ce_L, long M, int np,
                                                            float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
                                                            float* rowloss, int32_t* rowcorrect) {
-    __shared__ RowFold sh[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long m = (long)blockIdx.x * 64 + lane;
+    __shared__ RowFold sh[FIN_GROUPS][FIN_ROWS];
+    const int r = threadIdx.x & (FIN_ROWS - 1), w = threadIdx.x / FIN_ROWS;
+    const long m = (long)blockIdx.x * FIN_ROWS + r;
     RowFold t = {-INFINITY, 0x7fffffff, -INFINITY, 0.f};
     if (m < M) {
-        for (int sl = w; sl < np; sl += 16) {
+        for (int sl = w; sl < np; sl += FIN_GROUPS) {
             const f32x4 q = part4[(long)sl * M + m];
             fold_push(t, q[0], __float_as_int(q[3]), q[2], q[1]);
         }
     }
-    sh[w][lane] = t;
+    sh[w][r] = t;
     __syncthreads();
     if (w == 0 && m < M) {
 #pragma unroll 1
-        for (int i = 1; i < 16; ++i) {
-            const RowFold o = sh[i][lane];
+        for (int i = 1; i < FIN_GROUPS; ++i) {
+            const RowFold o = sh[i][r];
             fold_push(t, o.m1, o.a1, o.m2, o.s);
         }
         const float lse = t.m1 + logf(t.s);
@@ -1373,7 +1375,7 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(1024), 0, st,
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, labels, B, L, M, ws.np,
                        lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
@@ -1400,7 +1402,7 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(1024), 0, st,
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
                        (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr);
     CAPDEC_LAUNCH_CHECK();
