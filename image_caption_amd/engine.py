@@ -52,7 +52,7 @@ class EngineOptions:
     mask_mode: str = "reference"                  # decoder.py:31-38 literally; "prefix_causal" / "none"
     activation: str = "relu"                      # decoder.py:60; "gelu" is an extension
     vocab_slab: int = 0                           # vocabulary columns per backward slab; 0: as wide as dl_budget_bytes allows
-    dl_budget_bytes: int = 2 << 30                # cap on the d(logits) slab buffer (the whole vocabulary fits at batch 256)
+    dl_budget_bytes: int = 16 << 30               # cap on the d(logits) slab buffer (the whole vocabulary fits up to batch 5000 per GPU)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
