@@ -278,11 +278,16 @@ class CaptionTrainer:
         self.reducer.begin()
         out = eng.loss_and_grads(self.W, self.grads, model._source(inputs), labels, train=model.training,
                                  step=self.step_count, pos=pos, want_grads=True, on_grad_ready=self.reducer.on_grad_ready)
-        self.reducer.finish()
         model._shadow.clear()      # module-mode shadows of the matrices are stale after this update
-        ops.adam_step(self.store.w, self.store.g, self.store.m, self.store.v, self.step_count, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay, grad_scale=1.0 / self.reducer.world_size,
-                      w_bf16=self.store.shadow if self.store.shadow is not self.store.w else None)
+        st = self.store
+
+        def adam(lo, hi):          # bucket boundaries are 64-element aligned: every slice stays 16-byte aligned
+            ops.adam_step(st.w[lo:hi], st.g[lo:hi], st.m[lo:hi], st.v[lo:hi], self.step_count, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, grad_scale=1.0 / self.reducer.world_size,
+                          w_bf16=st.shadow[lo:hi] if st.shadow is not st.w else None)
+        # one launch over the flat buffer on a single GPU; with several, one launch per all-reduce bucket, so
+        # that the update of the vocabulary matrix overlaps the reduction of the last bucket
+        self.reducer.drain(adam)
         return out
 
     @torch.no_grad()

@@ -89,14 +89,30 @@ class GradReducer:
         if self.overlap and self.ready_end - self.sent_end >= self.bucket_elems:
             self._launch(self.ready_end)
 
-    def finish(self):
-        if not self.enabled:
-            return
+    def _launch_rest(self):
         self._launch(self.store.numel if self.ready_end >= self.store.numel else self.ready_end)
         if self.sent_end < self.store.numel:          # anything never announced (defensive)
             self._launch(self.store.numel)
+
+    def finish(self):
+        if not self.enabled:
+            return
+        self._launch_rest()
         for w in self.works:
             w.wait()
+        self.works = []
+
+    def drain(self, apply):
+        """finish(), bucket by bucket: ``apply(start, end)`` is called for each bucket, in buffer order, as
+        soon as the current stream has been ordered after THAT bucket's all-reduce.  The optimiser update of
+        the early buckets (the vocabulary matrix) thus runs while the last bucket is still being reduced."""
+        if not self.enabled:
+            apply(0, self.store.numel)
+            return
+        self._launch_rest()
+        for w, (a, b) in zip(self.works, self.bucket_log):
+            w.wait()
+            apply(a, b)
         self.works = []
 
 

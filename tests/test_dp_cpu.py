@@ -32,7 +32,12 @@ def _worker(rank, world, port, overlap, q):
             red.on_grad_ready(HEAD_B, 0, V)
             for i in (1, 0):
                 red.on_grad_ready(("block", i), 0, 0)
-            red.finish()
+            if step == 0:
+                red.finish()
+            else:                                             # bucket-by-bucket completion: every element handed over once, in order
+                seen = []
+                red.drain(lambda a, b: seen.append((a, b)))
+                assert seen == red.bucket_log and seen[0][0] == 0 and seen[-1][1] == st.numel
             want = (torch.arange(st.numel, dtype=torch.float32) % 97) * world + sum((r + 1) * 1000 + step for r in range(world))
             assert torch.equal(st.g, want), "all-reduce result wrong"
             log = red.bucket_log
