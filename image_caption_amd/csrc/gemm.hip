@@ -553,10 +553,10 @@ __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float
 // the bias, and for the cross-entropy epilogues -inf past N (such columns never win a max and add
 // exp(-inf) = 0), which leaves the row loops free of bias loads and bounds checks.
 template <int EPI>
-__device__ __forceinline__ void load_col_consts(const GemmArgs& p, int n0, int wave, int lane, float (&cb)[4]) {
+__device__ __forceinline__ void load_col_consts(const GemmArgs& p, int n0, int wc, int lane, float (&cb)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
         const float past = (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) ? -INFINITY : 0.f;
         cb[j] = n < p.N ? (p.bias ? p.bias[n] : 0.f) : past;
     }
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
 
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
     float cb[4];
-    load_col_consts<EPI>(p, n0, wave, lane, cb);
+    load_col_consts<EPI>(p, n0, wave & 1, lane, cb);
     stage_acc(smem, acc, cb, wave, lane);
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -750,22 +750,27 @@ __device__ __forceinline__ void dma_tile(const OperandView& v, const unsigned* o
     for (int j = 0; j < NJ; ++j) dma_piece(rs, off[j], tile + (NW * j + wave) * 1024);
 }
 
-// Geometry <WM, TI, NST>: 2*WM waves in a WM x 2 grid, each wave TI x 4 MFMA tiles (16*TI rows x 64
-// columns), NST ring stages.
-//   <2,4,4>  128x128, 4 waves, 2 workgroups/CU: small grids and reduction-major operands
-//   <2,8,3>  256x128, 4 waves of 128x64, 2 workgroups/CU: per MFMA a quarter fewer DMA pieces and LDS
-//            reads than 128x128 (whose 16 KiB per 32-deep step needs the CU's whole 64 B/clk fill path),
-//            and the co-resident workgroup's main loop covers this one's epilogue
-//   <4,4,4>  256x128, 8 waves of 64x64, 1 workgroup/CU
-// A reduction-major A image wider than 128 columns is stored as two 128-column sub-images.
-template <int WM, int TI, int NST> struct DmaGeo {
-    static constexpr int NW = 2 * WM;                       // waves
+// Geometry <WM, WN, TI, NST>: WM x WN waves, each wave TI x 4 MFMA tiles (16*TI rows x 64 columns),
+// NST ring stages.
+//   <2,2,4,4>  128x128, 4 waves, 2 workgroups/CU: small grids
+//   <2,2,8,3>  256x128, 4 waves of 128x64, 2 workgroups/CU: per MFMA a quarter fewer DMA pieces and LDS
+//              reads than 128x128 (whose 16 KiB per 32-deep step needs the CU's whole 64 B/clk fill path),
+//              and the co-resident workgroup's main loop covers this one's epilogue (K = 768 products)
+//   <2,4,8,4>  256x256, 8 waves of 128x64, 1 workgroup/CU, 4 stages: half the operand bytes per MFMA of
+//              256x128 and a deeper ring, for the deep-K products (head dgrad / wgrad) whose waves
+//              otherwise spend half their time parked on the stage wait
+//   <4,2,4,4>  256x128, 8 waves of 64x64, 1 workgroup/CU (diagnostic)
+// A reduction-major image wider than 128 columns is stored as 128-column sub-images.
+template <int WM, int WN, int TI, int NST> struct DmaGeo {
+    static constexpr int NW = WM * WN;                      // waves
     static constexpr int WROWS = 16 * TI;                   // rows per wave
     static constexpr int BMV = WM * WROWS;                  // tile rows
+    static constexpr int BNV = WN * 64;                     // tile columns
     static constexpr int A_BYTES = BMV * 64;                // one 32-deep A image
-    static constexpr int STAGE = A_BYTES + DTILE_BYTES;
+    static constexpr int B_BYTES = BNV * 64;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
     static constexpr int NJA = A_BYTES / 1024 / NW;         // A pieces per wave
-    static constexpr int NJB = 8 / NW;                      // B pieces per wave
+    static constexpr int NJB = B_BYTES / 1024 / NW;         // B pieces per wave
     static constexpr int INFLIGHT = (NST - 2) * (NJA + NJB);// DMA instructions that may stay outstanding at the wait
     static constexpr int RING = NST * STAGE;
     static constexpr int CSTAGE = NW * CS_WAVE_BYTES;
@@ -773,17 +778,17 @@ template <int WM, int TI, int NST> struct DmaGeo {
     static constexpr int WG_PER_CU = 2 * LDS <= 160 * 1024 && NW == 4 ? 2 : 1;
 };
 
-template <bool A_TR, bool B_TR, int EPI, int WM, int TI, int NST>
-__global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void gemm_bf16_dma_kernel(GemmArgs p) {
+template <bool A_TR, bool B_TR, int EPI, int WM, int WN, int TI, int NST>
+__global__ __launch_bounds__(64 * WM * WN, (DmaGeo<WM, WN, TI, NST>::WG_PER_CU)) void gemm_bf16_dma_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = DmaGeo<WM, TI, NST>;
-    const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + BN - 1) / BN;
+    using G = DmaGeo<WM, WN, TI, NST>;
+    const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + G::BNV - 1) / G::BNV;
     int tile_m, tile_n;
     map_tile(tm, tn, tile_m, tile_n);
-    const int m0 = tile_m * G::BMV, n0 = tile_n * BN;
+    const int m0 = tile_m * G::BMV, n0 = tile_n * G::BNV;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     OperandView va, vb;
     if (A_TR) { va.base = (const bf16_t*)p.A + m0; va.remaining = (long)p.K * p.lda - m0; }
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void ge
     for (int j = 0; j < G::NJB; ++j) offb[j] = dma_src_offset<B_TR>(vb, G::NW * j + wave, lane);
 
     float cb[4];                             // column constants of the epilogue: fetched now, used after the main loop
-    load_col_consts<EPI>(p, n0, wave, lane, cb);
+    load_col_consts<EPI>(p, n0, wc, lane, cb);
     f32x4 acc[TI][4];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(128 * WM, (DmaGeo<WM, TI, NST>::WG_PER_CU)) void ge
         stage_acc(smem, acc + 4 * h, cb, wave, lane);
         if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 3 + 2 * h] = __builtin_amdgcn_s_memtime();
         run_epilogue_at<EPI>(p, reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES), m0 + wr * G::WROWS + h * 64, n0 + wc * 64,
-                             tile_n * 2 + wc, lane);
+                             (n0 >> 6) + wc, lane);
         if (p.stamps && tid == 0 && h == 0) p.stamps[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
     }
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -949,7 +954,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ launch
 unsigned long long* g_stamps = nullptr;
-int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves)
+int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256)
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
@@ -969,7 +974,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         // fragment) it wins where the grid is large and K deep (the vocabulary-sized dgrad / wgrad), while
         // the small split-K weight gradients of the block measured faster on the register-staged kernel.
         // The 256-row geometry needs at least one workgroup per CU.
-        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG };
+        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG, KERN_WIDE };
         const bool any_km = a.a_kmajor || a.b_kmajor;
         const bool ring_ok = a.K >= DBK && ((a.K % DBK) == 0 || (a.a_kmajor && a.b_kmajor));
         const int split = a.split_k > 1 ? a.split_k : 1;
@@ -982,14 +987,18 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             if (big_tiles >= 512) kern = KERN_TALL;
             else if (nwg >= 256 && a.K >= 2048 && split == 1) kern = KERN_RING128;
         }
+        const long wide_tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        // deep-K plain products: 256x256 tiles, one workgroup per CU, as soon as every CU gets one
+        if (EPI == EPI_STD && ring_ok && a.K >= 2048 && wide_tiles * split >= 256) kern = KERN_WIDE;
         if (g_gemm_mode == 1) kern = KERN_REG;
+        else if (g_gemm_mode == 5 && ring_ok && EPI == EPI_STD) kern = KERN_WIDE;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
         else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
-#define CAPDEC_RING_LAUNCH(AT, BT, WM, TI, NST, NWG)                                                   \
+#define CAPDEC_RING_LAUNCH(AT, BT, WM, WN, TI, NST, NWG)                                               \
     do {                                                                                               \
-        using G = DmaGeo<WM, TI, NST>;                                                                 \
-        auto kfn = gemm_bf16_dma_kernel<AT, BT, EPI, WM, TI, NST>;                                     \
+        using G = DmaGeo<WM, WN, TI, NST>;                                                             \
+        auto kfn = gemm_bf16_dma_kernel<AT, BT, EPI, WM, WN, TI, NST>;                                 \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); \
@@ -999,7 +1008,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
     } while (0)
 #define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
     do {                                                                                               \
-        if (kern == KERN_RING128) CAPDEC_RING_LAUNCH(AT, BT, 2, 4, 4, nwg);                            \
+        if (kern == KERN_RING128) CAPDEC_RING_LAUNCH(AT, BT, 2, 2, 4, 4, nwg);                            \
         else {                                                                                         \
             static bool attr_set = false;                                                              \
             if (!attr_set) {                                                                           \
@@ -1010,12 +1019,19 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);        \
         }                                                                                              \
     } while (0)
-        if (kern == KERN_TALL) {
-            if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 8, 3, big_tiles);
-            else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 8, 3, big_tiles);
-            else if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 8, 3, big_tiles);
-            else CAPDEC_RING_LAUNCH(false, false, 2, 8, 3, big_tiles);
-        } else if (kern == KERN_BIG) CAPDEC_RING_LAUNCH(false, false, 4, 4, 4, big_tiles);
+        if (kern == KERN_WIDE) {
+            if constexpr (EPI == EPI_STD) {
+                if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 4, 8, 4, wide_tiles);
+                else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 4, 8, 4, wide_tiles);
+                else if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 4, 8, 4, wide_tiles);
+                else CAPDEC_RING_LAUNCH(false, false, 2, 4, 8, 4, wide_tiles);
+            }
+        } else if (kern == KERN_TALL) {
+            if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 2, 8, 3, big_tiles);
+            else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 2, 8, 3, big_tiles);
+            else if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 2, 8, 3, big_tiles);
+            else CAPDEC_RING_LAUNCH(false, false, 2, 2, 8, 3, big_tiles);
+        } else if (kern == KERN_BIG) CAPDEC_RING_LAUNCH(false, false, 4, 2, 4, 4, big_tiles);
         else if (!a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(false, false);
         else if (!a.a_kmajor && a.b_kmajor) CAPDEC_GEMM_CASE(false, true);
         else if (a.a_kmajor && !a.b_kmajor) CAPDEC_GEMM_CASE(true, false);
@@ -1292,13 +1308,20 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 512 && nkt >= 32) {
         // the split that best fills whole rounds of the 512 resident workgroups (two per CU), counted in the
         // tiles of the kernel that will run; the smallest such split, since every slab is written and re-read
+        const bool ring_ok = (a.K % 32) == 0 || (a.a_kmajor && a.b_kmajor);
+        const long wide = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        const long maxsp = nkt / 8 < 8 ? nkt / 8 : 8;
+        // 256x256 tiles (one workgroup per CU) when some split gives every CU one; else 256x128 / 128x128 tiles
+        const bool wide_possible = ring_ok && a.K >= 2048 && wide * maxsp >= 256;
         const bool tall_possible = !a.a_kmajor && a.K >= 512 && (a.K % 32) == 0;
-        const long unit = tall_possible ? (long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) : tiles;
+        const long unit = wide_possible ? wide : (tall_possible ? (long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) : tiles);
+        const long resident = wide_possible ? 256 : 512;
         long split = 1;
         double best = 0.0;
-        for (long sp = 1; sp <= 8 && sp <= nkt / 8; ++sp) {
+        for (long sp = 1; sp <= maxsp; ++sp) {
             const long n = unit * sp;
-            const double eff = (double)n / (double)((n + 511) / 512 * 512);
+            if (wide_possible && n < 256) continue;
+            const double eff = (double)n / (double)((n + resident - 1) / resident * resident);
             if (eff > best + 0.03) { best = eff; split = sp; }
         }
         const long slab = (long)a.M * a.N;

@@ -101,7 +101,7 @@ def main():
     t_with = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws), 20)
     t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
     print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
-    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU)")
+    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU) | ring 256x256 (plain products only)")
     Vp = (V + 127) // 128 * 128
     dlw = torch.zeros(Mt, Vp, device=DEV, dtype=BF)
     dlw[:, :V] = (torch.randn(Mt, V, device=DEV, generator=g) * 1e-3).to(BF)
@@ -117,24 +117,24 @@ def main():
         "dgrad KV 58624x768x1536 (B kmajor)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, w_kv, dh1, b_kmajor=True)),
         "wgrad KV 1536x768x58624 (A,B kmajor, split-K)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, x_all, gkv, a_kmajor=True, b_kmajor=True, workspace=skws)),
     }
-    print("reduction-major operands: register | ring128 | ring256 (4 waves) | default")
+    print("reduction-major operands: register | ring128 | ring 256x128 | ring 256x256 | default")
     for name, (fl, fn) in kcases.items():
-        res = {1: [], 2: [], 4: [], 0: []}
+        res = {1: [], 2: [], 4: [], 5: [], 0: []}
         for _ in range(5):
-            for mode in (1, 2, 4, 0):
+            for mode in (1, 2, 4, 5, 0):
                 lib.capdecdbg_gemm_mode(mode)
                 res[mode].append(fl / timeit(fn, 5) / 1e9)
         lib.capdecdbg_gemm_mode(0)
-        print(f"{name:48s} " + " | ".join(f"{sorted(res[m])[2]:7.1f}" for m in (1, 2, 4, 0)))
+        print(f"{name:48s} " + " | ".join(f"{sorted(res[m])[2]:7.1f}" for m in (1, 2, 4, 5, 0)))
     for name, (fl, fn) in cases.items():
-        res = {1: [], 2: [], 3: [], 4: []}
+        res = {1: [], 2: [], 3: [], 4: [], 5: []}
         for _ in range(5):
-            for mode in (1, 2, 3, 4):
+            for mode in (1, 2, 3, 4, 5):
                 lib.capdecdbg_gemm_mode(mode)
                 res[mode].append(fl / timeit(fn, 5) / 1e9)
         lib.capdecdbg_gemm_mode(0)
         med = {m: sorted(v)[2] for m, v in res.items()}
-        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f} | {med[4]:7.1f}")
+        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f} | {med[4]:7.1f} | {med[5]:7.1f}")
 
 
 if __name__ == "__main__":
