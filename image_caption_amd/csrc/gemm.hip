@@ -389,7 +389,7 @@ __device__ __forceinline__ void epilogue_ce_fwd(const GemmArgs& p, float* cs, in
         for (int e = 0; e < 4; ++e) { ev[e] = __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, nref)); sum += ev[e]; }
         if (p.C) *reinterpret_cast<f32x4*>(row + c4 * 4) = ev;       // kept for the store pass below
     }
-    if (live) p.part4[(long)slot * p.M + m] = f32x4{m1, sum, m2, __int_as_float(a1)};
+    if (live && slot < p.np) p.part4[(long)slot * p.M + m] = f32x4{m1, sum, m2, __int_as_float(a1)};
     if (!p.C) return;
     // exp(z - slot max), the numerators of the softmax, go out for the backward (which then needs no second
     // product over the vocabulary): W consecutive columns per lane, one 16-byte store per row

@@ -98,6 +98,8 @@ def main():
         "linear1 8192x2048x768": (2.0 * Mt * ff * d, lambda: ops.gemm(x_t, w1, a1, bias=bias_ff, act=_lib.ACT_RELU, drop=drop)),
         "square 8192^3": (2.0 * 8192 ** 3, lambda: ops.gemm(a8, b8, c8)),
     }
+    probs = torch.empty(Mt, (V + 127) // 128 * 128, device=DEV, dtype=BF)
+    cases["logits+CE fwd keeping numerators"] = (2.0 * Mt * V * d, lambda: ops.logits_ce_fwd(x_t, wv, bias_v, labels, B, L, lse, amax, ls, cr, ws, probs=probs))
     t_with = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws), 20)
     t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
     print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
