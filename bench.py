@@ -115,9 +115,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    rehearse = world == 1 and os.environ.get("CAPDEC_DP_SINGLE_RANK", "0") == "1"
+    json_out = sys.stdout
+    if world > 1 or rehearse:
+        # RCCL prints a version banner on file descriptor 1 at communicator set-up: keep stdout for the one
+        # JSON line, and send everything else that is written to descriptor 1 to stderr
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from image_caption_amd.decoder import CaptionTrainer, TransformerDecoder
     from image_caption_amd.engine import EngineOptions, KernelTimer
@@ -139,7 +150,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +168,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     model.engine.timer = None
-    if world > 1:
+    if world > 1 or rehearse:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,8 +233,8 @@ def main():
             result["greedy"] = greedy_bench(model, dev, args)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        print(json.dumps(result), file=json_out, flush=True)
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

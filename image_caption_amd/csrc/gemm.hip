@@ -549,30 +549,36 @@ __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float
     }
 }
 
-// Column constants of a wave's tile, in accumulator layout (a lane holds only 4 distinct columns):
-// the bias, and for the cross-entropy epilogues -inf past N (such columns never win a max and add
-// exp(-inf) = 0), which leaves the row loops free of bias loads and bounds checks.
+// The MFMAs are issued with the operands swapped (B fragment first), so that a lane holds
+//   C[row = lane & 15][cols 4*(lane>>4) .. +3]   of each 16x16 tile:
+// four CONSECUTIVE columns of one row, which go to the row-major LDS tile as one 16-byte write.
+//
+// Column constants of a wave's tile in that layout (a lane holds 16 distinct columns): the bias, and for
+// the cross-entropy epilogues -inf past N (such columns never win a max and add exp(-inf) = 0), which
+// leaves the row loops free of bias loads and bounds checks.
 template <int EPI>
-__device__ __forceinline__ void load_col_consts(const GemmArgs& p, int n0, int wc, int lane, float (&cb)[4]) {
+__device__ __forceinline__ void load_col_consts(const GemmArgs& p, int n0, int wc, int lane, f32x4 (&cb)[4]) {
+    const float past = (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) ? -INFINITY : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
-        const float past = (EPI == EPI_CE_FWD || EPI == EPI_CE_BWD) ? -INFINITY : 0.f;
-        cb[j] = n < p.N ? (p.bias ? p.bias[n] : 0.f) : past;
+        const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
+        if (p.bias && n + 3 < p.N && (reinterpret_cast<uintptr_t>(p.bias + n) & 15) == 0) {
+            cb[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cb[j][r] = n + r < p.N ? (p.bias ? p.bias[n + r] : 0.f) : past;
+        }
     }
 }
 
-// Accumulators (+ column constants) -> the wave's LDS tile.  A lane holds
-// C[row = 4*(lane>>4) + r][col = lane & 15] of each 16x16 tile.
-__device__ __forceinline__ void stage_acc(char* smem, const f32x4 (*acc)[4], const float (&cb)[4], int wave, int lane) {
+// Accumulators (+ column constants) -> the wave's LDS tile: 16 writes of 16 bytes per 64 rows.
+__device__ __forceinline__ void stage_acc(char* smem, const f32x4 (*acc)[4], const f32x4 (&cb)[4], int wave, int lane) {
     float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                cs[(i * 16 + 4 * (lane >> 4) + r) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][r] + cb[j];
+            *reinterpret_cast<f32x4*>(cs + (i * 16 + (lane & 15)) * CS_LD + j * 16 + 4 * (lane >> 4)) = acc[i][j] + cb[j];
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
     __builtin_amdgcn_wave_barrier();
 }
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);     // swapped: see stage_acc
         }
         if (more) {
             char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
-    float cb[4];
+    f32x4 cb[4];
     load_col_consts<EPI>(p, n0, wave & 1, lane, cb);
     stage_acc(smem, acc, cb, wave, lane);
     run_epilogue<EPI>(p, smem, m0, n0, tile_n, wave, lane);
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(64 * WM * WN, (DmaGeo<WM, WN, TI, NST>::WG_PER_CU))
 #pragma unroll
     for (int j = 0; j < G::NJB; ++j) offb[j] = dma_src_offset<B_TR>(vb, G::NW * j + wave, lane);
 
-    float cb[4];                             // column constants of the epilogue: fetched now, used after the main loop
+    f32x4 cb[4];                             // column constants of the epilogue: fetched now, used after the main loop
     load_col_consts<EPI>(p, n0, wc, lane, cb);
     f32x4 acc[TI][4];
 #pragma unroll
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(64 * WM * WN, (DmaGeo<WM, WN, TI, NST>::WG_PER_CU))
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);     // swapped: see stage_acc
             if (i < NP) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < G::NJA) dma_piece(rsa, offa[i], wst + (G::NW * i + wave) * 1024);

@@ -17,6 +17,7 @@ before the optimiser kernel reads the gradients.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -33,8 +34,11 @@ class GradReducer:
     def __init__(self, store, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
         self.store = store
         self.group = process_group
+        # CAPDEC_DP_SINGLE_RANK=1 keeps the exchange on with one rank (every all-reduce is then an identity):
+        # a rehearsal of the RCCL call pattern on a one-GPU machine
+        single_ok = os.environ.get("CAPDEC_DP_SINGLE_RANK", "0") == "1"
         self.enabled = bool(dist is not None and dist.is_available() and dist.is_initialized()
-                            and dist.get_world_size(process_group) > 1)
+                            and (dist.get_world_size(process_group) > 1 or single_ok))
         self.world_size = dist.get_world_size(process_group) if self.enabled else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
