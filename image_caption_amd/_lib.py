@@ -80,6 +80,26 @@ class AttnBwdDesc(C.Structure):
     ]
 
 
+class BlockParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "norm1_w", "norm1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm2_w", "norm2_b",
+        "linear1_w", "linear1_b", "linear2_w", "linear2_b", "kv_cache")]
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [
+        ("B", c_int), ("d_model", c_int), ("nhead", c_int), ("dim_ff", c_int), ("vocab", c_int), ("n_blocks", c_int), ("smax", c_int),
+        ("dtype", c_int), ("activation", c_int), ("ln_eps", c_float),
+        ("blocks", C.POINTER(BlockParams)),
+        ("head_w", c_void_p), ("head_b", c_void_p), ("ld_head_w", c_long),
+        ("emb", c_void_p), ("pos", c_void_p),
+        ("x_last", c_void_p), ("ids", c_void_p), ("done", c_void_p), ("out", c_void_p), ("margin", c_void_p),
+        ("max_len", c_int), ("t", c_int), ("s_new", c_int),
+        ("eos_id", C.c_int64), ("pad_id", C.c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_long),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/capdec.h declares
 SIGNATURES = {
     "capdec_abi_version": (c_int, []),
@@ -121,6 +141,8 @@ SIGNATURES = {
     "capdec_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "capdec_greedy_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_int64, C.c_int64, c_void_p]),
+    "capdec_decode_step_workspace": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "capdec_decode_step": (c_int, [C.POINTER(DecodeDesc), c_void_p]),
 }
 
 _lib = None

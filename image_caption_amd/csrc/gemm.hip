@@ -826,7 +826,12 @@ __global__ __launch_bounds__(64 * WM * WN, (DmaGeo<WM, WN, TI, NST>::WG_PER_CU))
         nk = max(0, min(kper, nk_total - kt0));
         p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
     }
-    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0) {
+        p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+        // where the workgroup runs: XCC_ID (register 20) in the high word, HW_ID (register 4: CU, SH, SE) in the low word
+        p.stamps[(long)blockIdx.x * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                             __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     // a stage index past the last k-tile still issues its (harmless) loads, so that the
     // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
     auto dma_stage = [&](int kt, int slot) {
@@ -960,6 +965,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ launch
 unsigned long long* g_stamps = nullptr;
+int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256)
 
 template <int EPI>
@@ -1007,10 +1013,11 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         auto kfn = gemm_bf16_dma_kernel<AT, BT, EPI, WM, WN, TI, NST>;                                 \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(64 * G::NW), G::LDS, st, a);       \
+        const int lds_bytes = G::LDS + g_extra_lds <= 160 * 1024 ? G::LDS + g_extra_lds : G::LDS;      \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(64 * G::NW), lds_bytes, st, a);    \
     } while (0)
 #define CAPDEC_GEMM_CASE(AT, BT)                                                                       \
     do {                                                                                               \
@@ -1263,11 +1270,32 @@ __global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int 
     }
 }
 
+// Diagnostic stand-in for a communication kernel that holds compute units while a product runs: every
+// workgroup spins until the constant-rate clock (100 MHz) has advanced by `ticks`, then exits.
+__global__ __launch_bounds__(256) void occupy_kernel(long ticks, int* sink) {
+    extern __shared__ char hold[];
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while ((long)(wall_clock64() - t0) < ticks) { __builtin_amdgcn_s_sleep(8); ++spins; }
+    if (sink && spins == 0xffffffffu) { hold[threadIdx.x] = 1; sink[0] = hold[0]; }     // never true: keeps the LDS allocation
+}
+
 }  // namespace
+
+// diagnostic hook (not part of the declared ABI): `wgs` workgroups of 256 threads with `lds_bytes` of LDS each
+// stay resident for `microseconds` on `stream`
+extern "C" int capdecdbg_occupy(int wgs, int lds_bytes, long microseconds, void* stream) {
+    if (wgs <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 100000) return 1;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 2;
+    hipLaunchKernelGGL(occupy_kernel, dim3(wgs), dim3(256), lds_bytes, (hipStream_t)stream, microseconds * 100, (int*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
 
 // diagnostic hook (not part of the declared ABI): clock stamps of every workgroup of the next GEMM launches
 extern "C" void capdecdbg_gemm_stamps(void* device_buffer) { g_stamps = (unsigned long long*)device_buffer; }
 extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
+extern "C" void capdecdbg_gemm_extra_lds(int bytes) { g_extra_lds = bytes > 0 ? bytes : 0; }
 
 // ==================================================================== C ABI
 extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {

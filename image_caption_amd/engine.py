@@ -55,6 +55,7 @@ class EngineOptions:
     dl_budget_bytes: int = 16 << 30               # cap on the d(logits) slab buffer (the whole vocabulary fits up to batch 5000 per GPU)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
+    composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     dropout_seed: int = 42
 
@@ -632,6 +633,65 @@ class DecoderEngine:
         out = torch.full((B, max_len), pad_id, dtype=torch.int64, device=dev)
         margins = torch.zeros(B, max_len, dtype=torch.float32, device=dev) if return_margins else None
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        if emb.dtype != torch.float32 or not emb.is_contiguous():
+            raise ValueError("the token-embedding table must be a contiguous float32 [vocab, d_model] tensor")
+        if self.timer is not None or not self.opt.composed_decode_step:
+            # per-kernel event brackets are wanted: issue the step's launches one by one (the same kernels,
+            # in the same order, as capdec_decode_step)
+            self._decode_loop_by_op(W, caches, x_last, emb, pos, ids, done, out, margins, max_len, S0, smax, eos_id, pad_id,
+                                    stop_check_every)
+            return (out, margins) if return_margins else out
+        mg = self.buf("gen_margin", (B,), torch.float32, dev)
+        # the residual stream of the newest row lives in one buffer that every step reads and rewrites
+        xl = self.buf("gen_xlast", (B, d), torch.float32, dev)
+        xl.copy_(x_last)
+        if pos is not None:
+            pos = pos.contiguous()
+            if pos.shape[0] < smax:
+                raise ValueError(f"pos has {pos.shape[0]} rows, decoding needs {smax}")
+        import ctypes as C
+        lib = _lib.load()
+        wsb = lib.capdec_decode_step_workspace(B, d, ff, V, _lib.dtype_code(caches[0]))
+        ws = self.buf("gen_step_ws", (wsb,), torch.uint8, dev)
+        blocks = (_lib.BlockParams * nb)()
+        for i in range(nb):
+            w = W.blocks[i]
+            for field, key in (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
+                               ("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
+                               ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),
+                               ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"),
+                               ("linear1_w", "linear1.weight"), ("linear1_b", "linear1.bias"),
+                               ("linear2_w", "linear2.weight"), ("linear2_b", "linear2.bias")):
+                setattr(blocks[i], field, w[key].data_ptr())
+            blocks[i].kv_cache = caches[i].data_ptr()
+        dd = _lib.DecodeDesc()
+        dd.B, dd.d_model, dd.nhead, dd.dim_ff, dd.vocab, dd.n_blocks, dd.smax = B, d, H, ff, V, nb, smax
+        dd.dtype, dd.activation, dd.ln_eps = _lib.dtype_code(caches[0]), _ACTS[self.opt.activation], 1e-5
+        dd.blocks = blocks
+        dd.head_w, dd.head_b, dd.ld_head_w = W.head_w.data_ptr(), W.head_b.data_ptr(), W.head_w.stride(0)
+        dd.emb, dd.pos = emb.data_ptr(), (pos.data_ptr() if pos is not None else None)
+        dd.x_last, dd.ids, dd.done, dd.out, dd.margin = xl.data_ptr(), ids.data_ptr(), done.data_ptr(), out.data_ptr(), mg.data_ptr()
+        dd.max_len, dd.eos_id, dd.pad_id = max_len, eos_id, pad_id
+        dd.workspace, dd.workspace_bytes = ws.data_ptr(), wsb
+        stream = _lib.stream_ptr()
+        for t in range(max_len):
+            dd.t, dd.s_new = t, S0 + t                               # s_new: index of the row appended after token t
+            with self._span("decode_step"):
+                _lib.check(lib.capdec_decode_step(C.byref(dd), stream), "capdec_decode_step")
+            if return_margins:
+                margins[:, t].copy_(mg)
+            # <eos> early stop: the remaining columns already hold <pad>.  Looking at `done` is a host
+            # synchronisation, so it is only done every stop_check_every steps (0: never).
+            if stop_check_every > 0 and t + 1 < max_len and (t + 1) % stop_check_every == 0 and bool(done.all().item()):
+                break
+        return (out, margins) if return_margins else out
+
+    def _decode_loop_by_op(self, W, caches, x_last, emb, pos, ids, done, out, margins, max_len, S0, smax, eos_id, pad_id,
+                           stop_check_every):
+        geo, cdt = self.geo, self.cdt
+        d, ff, H, hd, V, nb = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd, geo.vocab_size, geo.n_blocks
+        B, dev, scale = ids.shape[0], ids.device, geo.hd ** -0.5
+        return_margins = margins is not None
         ws = self.buf("gen_ws", (ops.logits_ce_workspace(B, V),), torch.uint8, dev)
         hh = self.buf("gen_hh", (B, d), cdt, dev)
         mg = self.buf("gen_margin", (B,), torch.float32, dev)
@@ -672,7 +732,6 @@ class DecoderEngine:
                 ops.gemm(a1s, w["linear2.weight"], xo[i % 2], bias=w["linear2.bias"], residual=xm)
                 xcur = xo[i % 2]
             x_last = xcur
-        return (out, margins) if return_margins else out
 
     def _attn_cache_fwd(self, q, cache, o, strides, B, H, S, hd, smax, q_start, nq, mask, prefix):
         import ctypes as C

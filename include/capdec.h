@@ -265,6 +265,48 @@ int capdec_adam_step(float* w, const float* g, float* m, float* v, long n, int s
 int capdec_greedy_update(int64_t* ids, uint8_t* done, int64_t* out, int B, int L, int t,
                          int64_t eos_id, int64_t pad_id, void* stream);
 
+/* ------------------------------------------------------------------ composed driver: one greedy step
+ * No reference counterpart (the reference has no generation); the block arithmetic is that of
+ * decoder.py:53-63 on one appended row, the scoring that of decoder.py:66 + an argmax.
+ * One call = token t of every sequence:
+ *   ids = argmax(x_last W_head^T + b_head); <eos>/<pad> book-keeping into out[:, t]  (as capdec_greedy_update);
+ *   then, unless t is the last token: row s_new = emb[ids] (+ pos[s_new]) goes through every block against
+ *   the K/V caches (its own K/V are appended at s_new) and x_last receives its hidden state.
+ * `blocks` is a HOST array of n_blocks entries of device pointers: matrices in `dtype`, vectors f32,
+ * kv_cache [B][H][2][smax][hd] in `dtype` already holding rows 0..s_new-1.
+ * workspace: capdec_decode_step_workspace(...) bytes, 256-byte aligned; nothing is allocated. */
+typedef struct {
+    const float* norm1_w; const float* norm1_b;
+    const void* in_proj_w; const float* in_proj_b;      /* [3d, d], [3d] */
+    const void* out_proj_w; const float* out_proj_b;    /* [d, d], [d] */
+    const float* norm2_w; const float* norm2_b;
+    const void* linear1_w; const float* linear1_b;      /* [ff, d], [ff] */
+    const void* linear2_w; const float* linear2_b;      /* [d, ff], [d] */
+    void* kv_cache;
+} capdec_block_params;
+
+typedef struct {
+    int B, d_model, nhead, dim_ff, vocab, n_blocks, smax;
+    int dtype;                   /* CAPDEC_BF16 / CAPDEC_F32: matrices, caches and internal activations */
+    int activation;              /* CAPDEC_ACT_* of the MLP */
+    float ln_eps;
+    const capdec_block_params* blocks;
+    const void* head_w; const float* head_b; long ld_head_w;   /* [vocab, d_model]; ld 0 = d_model */
+    const float* emb;            /* token-embedding table [vocab, d_model] f32 */
+    const float* pos;            /* optional [smax, d_model] f32 positional rows, or NULL */
+    float* x_last;               /* [B, d_model] f32: hidden state of the newest row (in / out) */
+    int64_t* ids;                /* [B] out: the chosen tokens */
+    uint8_t* done;               /* [B] in / out */
+    int64_t* out;                /* [B, max_len] */
+    float* margin;               /* optional [B]: top1 - top2 logit */
+    int max_len, t, s_new;
+    int64_t eos_id, pad_id;
+    void* workspace; long workspace_bytes;
+} capdec_decode_desc;
+
+long capdec_decode_step_workspace(int B, int d_model, int dim_ff, int vocab, int dtype);
+int capdec_decode_step(const capdec_decode_desc* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -347,6 +347,51 @@ def test_greedy_multi_block_matches_oracle():
         make_model(sh, full, F32, n_blocks=nb).generate(img.to(DEV), sos.to(DEV), emb.to(DEV), max_len=4)
 
 
+def test_decode_step_driver_equals_the_launch_by_launch_loop():
+    """capdec_decode_step composes the same kernels the per-kernel loop issues: ids and margins agree bit for bit."""
+    from image_caption_amd.engine import KernelTimer
+    sh = TINY
+    nb = 2
+    sds = [helpers.make_state_dict(sh, seed=950 + i, head_gain=4.0) for i in range(nb)]
+    full = dict(sds[0])
+    for k in ref_cpu.BLOCK_KEYS:
+        full[block_key(1, k, nb)] = sds[1][k]
+    img, sos, _, _ = helpers.make_embeddings(sh, seed=1717)
+    emb = helpers.make_token_table(sh, seed=1818)
+    pos = 0.3 * torch.randn(sh.S, sh.d, generator=torch.Generator().manual_seed(8))
+    for dtype in (F32, BF16):
+        model = make_model(sh, full, dtype, n_blocks=nb, mask_mode="prefix_causal", activation="gelu")
+        model.eval()
+        args = (img.to(DEV), sos.to(DEV), emb.to(DEV))
+        ids_a, mg_a = model.generate(*args, max_len=sh.L, pos=pos.to(DEV), return_margins=True)
+        model.engine.timer = KernelTimer()                  # with a timer attached generate() launches kernel by kernel
+        ids_b, mg_b = model.generate(*args, max_len=sh.L, pos=pos.to(DEV), return_margins=True)
+        model.engine.timer = None
+        assert torch.equal(ids_a, ids_b) and torch.equal(mg_a, mg_b)
+
+
+def test_decode_step_rejects_bad_descriptors():
+    import ctypes as C
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    dd = _lib.DecodeDesc()
+    assert lib.capdec_decode_step(C.byref(dd), None) == -1          # CAPDEC_ERR_INVALID: empty geometry
+    assert b"geometry" in lib.capdec_last_error()
+    assert lib.capdec_decode_step_workspace(0, 768, 2048, 50260, _lib.BF16) == 0
+    need = lib.capdec_decode_step_workspace(4, 64, 128, 100, _lib.F32)
+    assert need > 0 and need % 256 == 0
+    blocks = (_lib.BlockParams * 1)()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    dd.B, dd.d_model, dd.nhead, dd.dim_ff, dd.vocab, dd.n_blocks, dd.smax = 4, 64, 4, 128, 100, 1, 16
+    dd.dtype, dd.blocks, dd.max_len, dd.t, dd.s_new = _lib.F32, blocks, 4, 0, 3
+    for f in ("head_w", "emb", "x_last", "ids", "done", "out"):
+        setattr(dd, f, buf.data_ptr())
+    dd.workspace, dd.workspace_bytes = buf.data_ptr(), 16
+    assert lib.capdec_decode_step(C.byref(dd), None) == -3          # CAPDEC_ERR_WORKSPACE
+    dd.t = 4
+    assert lib.capdec_decode_step(C.byref(dd), None) == -1 and b"token index" in lib.capdec_last_error()
+
+
 # ---------------------------------------------------------------------------- drop-in surface
 def test_prefix_join_and_process_batch():
     from image_caption_amd.img_text_concat import process_batch
