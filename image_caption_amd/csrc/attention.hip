@@ -21,6 +21,7 @@ struct AttnArgs {
     const void* q; const void* k; const void* v; void* o;
     long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_hs, o_ss;
     int B, H, S, hd, q_start, nq, mask_mode, open_cols;
+    int S4;                // S rounded up to a multiple of 4: row stride of the dropout index space
     uint32_t drop_thr, drop_k0, drop_k1; float drop_scale;
     float* lse;
     // backward
@@ -44,25 +45,56 @@ template <int HD> struct Geo {
 
 // rows [row0, row0+nvalid) of a strided [*, HD] bf16 matrix -> LDS, zero rows up to npad;
 // four 16-byte loads per thread are in flight before the first LDS write
-template <int HD>
+template <int HD, int U = 4>
 __device__ __forceinline__ void rows_to_lds(char* lds, const bf16_t* base, long sstride, int row0, int nvalid, int npad,
                                             int tid, int nthreads) {
     constexpr int CPR = Geo<HD>::CPR, ROWB = Geo<HD>::ROWB;
     const int total = npad * CPR;
-    for (int c0 = tid; c0 < total; c0 += 4 * nthreads) {
-        u32x4 v[4];
+    for (int c0 = tid; c0 < total; c0 += U * nthreads) {
+        u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int c = c0 + u * nthreads;
             const int row = c / CPR, ch = c - row * CPR;
             v[u] = u32x4{0, 0, 0, 0};
             if (c < total && row < nvalid) v[u] = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * sstride + ch * 8);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int c = c0 + u * nthreads;
             const int row = c / CPR, ch = c - row * CPR;
             if (c < total) *reinterpret_cast<u32x4*>(lds + row * ROWB + ch * 16) = v[u];
+        }
+    }
+}
+
+// two matrices of the same shape at once (the whole-sequence kernels): all loads of both are in flight before the
+// first LDS write, so a workgroup that has the compute unit to itself pays one memory latency per batch, not two
+template <int HD, int U>
+__device__ __forceinline__ void rows_to_lds2(char* lds0, const bf16_t* base0, long ss0, char* lds1, const bf16_t* base1, long ss1,
+                                             int row0, int nvalid, int npad, int tid, int nthreads) {
+    constexpr int CPR = Geo<HD>::CPR, ROWB = Geo<HD>::ROWB;
+    const int total = npad * CPR;
+    for (int c0 = tid; c0 < total; c0 += U * nthreads) {
+        u32x4 v0[U], v1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int row = c / CPR, ch = c - row * CPR;
+            v0[u] = v1[u] = u32x4{0, 0, 0, 0};
+            if (c < total && row < nvalid) {
+                v0[u] = *reinterpret_cast<const u32x4*>(base0 + (long)(row0 + row) * ss0 + ch * 8);
+                v1[u] = *reinterpret_cast<const u32x4*>(base1 + (long)(row0 + row) * ss1 + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int row = c / CPR, ch = c - row * CPR;
+            if (c < total) {
+                *reinterpret_cast<u32x4*>(lds0 + row * ROWB + ch * 16) = v0[u];
+                *reinterpret_cast<u32x4*>(lds1 + row * ROWB + ch * 16) = v1[u];
+            }
         }
     }
 }
@@ -113,9 +145,23 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// the value quad lane R holds, in all four lanes of every aligned quad
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, R * 0x55, 0xF, 0xF, true); }
+
+constexpr float ATT_LOG2E = 1.4426950408889634f;
+// keys [0, key_limit) are the visible ones for query q: a prefix, in every mask mode
+__device__ __forceinline__ int key_limit(int q, int S, int mask_mode, int open_cols) {
+    return mask_mode == CAPDEC_MASK_NONE ? S : min(S, max(q + 1, open_cols));
+}
+
 // ================================================================== forward (bf16 MFMA)
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
+// SEQ = false: a workgroup owns up to 64 queries of one (sequence, head); K fragments come from global memory.
+// SEQ = true (long query ranges): ONE workgroup of 8 waves owns the whole (sequence, head); K and V are both
+// staged in LDS once and every wave walks the query tiles wave, wave + 8, ...  K, V, Q and O then cross the
+// memory system once per head instead of once per 64-query slab (V) and once per wave (K).
+template <int HD, bool SEQ>
+__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -123,14 +169,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
     const int SP = (p.S + 63) & ~63;
     const int nthreads = blockDim.x;
     char* Vl = smem;
+    char* Kl = smem + SP * G::ROWB;                                   // SEQ only
     const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
     bf16x8 kf[4][G::KS];
-    frags_from_global<HD>(kbase, p.k_ss, 0, p.S, lane, kf);       // first key block, in flight during the staging of V
-    rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
+    if constexpr (!SEQ) frags_from_global<HD>(kbase, p.k_ss, 0, p.S, lane, kf);       // first key block, in flight during the staging of V
+    if constexpr (SEQ) rows_to_lds2<HD, 8>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
+    else rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
     __syncthreads();
-    const int qw = p.q_start + blockIdx.y * (nthreads >> 2) + wave * 16;       // first query of this wave
     const int qend = min(p.q_start + p.nq, p.S);
-    if (qw >= qend) return;
+    const int qstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);         // SEQ: the wave's next query tile
+    for (int qw = p.q_start + (SEQ ? 0 : blockIdx.y * (nthreads >> 2)) + wave * 16; qw < qend; qw += qstep) {
     const int q = qw + i;
     const bool qok = q < qend;
     const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
@@ -141,55 +189,58 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
     float m_run = -INFINITY, l_run = 0.f;
-    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S4);       // a multiple of 4, as are the key bases below
+    const int klim = key_limit(q, p.S, p.mask_mode, p.open_cols);           // this lane's query sees keys < klim
+    const int klim_wave = key_limit(qw, p.S, p.mask_mode, p.open_cols);     // the smallest limit in the wave (its first query)
 
     for (int kb = 0; kb < SP; kb += 64) {
-        bf16x8 kn[4][G::KS];
-        if (kb + 64 < SP) frags_from_global<HD>(kbase, p.k_ss, kb + 64, p.S, lane, kn);      // next key block
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+            for (int ks = 0; ks < G::KS; ++ks) {
+                if constexpr (SEQ) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s[t], 0, 0, 0);
+                else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+            }
         }
-        if (kb + 64 < SP) {
+        if constexpr (!SEQ) {
+            // the next key block's fragments replace the ones just consumed; the softmax and the P V products
+            // below cover their latency
+            if (kb + 64 < SP) frags_from_global<HD>(kbase, p.k_ss, kb + 64, p.S, lane, kf);
+        }
+        // masking only in key blocks that some query of the wave does not see entirely (a wave-uniform test)
+        if (kb + 64 > klim_wave) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks) kf[t][ks] = kn[t][ks];
+                for (int r = 0; r < 4; ++r) s[t][r] = kb + t * 16 + 4 * g + r < klim ? s[t][r] : -INFINITY;
         }
-        float bm = -INFINITY;
+        float bm = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + t * 16 + 4 * g + r;
-                if (!key_visible(q, key, p.S, p.mask_mode, p.open_cols)) s[t][r] = -INFINITY;
-                bm = fmaxf(bm, s[t][r]);
-            }
+        for (int t = 1; t < 4; ++t) bm = fmaxf(bm, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
         bm = quad_max(bm);
         const float m_new = fmaxf(m_run, bm);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * ATT_LOG2E);
+        const float nm2 = -m_use * ATT_LOG2E;
         l_run *= alpha;
 #pragma unroll
         for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
         m_run = m_new;
         bf16x8 pf[2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            bool keep[4] = {true, true, true, true};
+            if (p.drop_thr) dropout_keep4(p.drop_k0, p.drop_k1, idx_row + kb + t * 16 + 4 * g, p.drop_thr, keep);     // the lane's 4 keys: one hash
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float pv = __expf(s[t][r] - m_use);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], ATT_LOG2E, nm2));
                 l_run += pv;
-                if (p.drop_thr) {
-                    const int key = kb + t * 16 + 4 * g + r;
-                    pv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? pv * p.drop_scale : 0.f;
-                }
-                pf[t >> 1][(t & 1) * 4 + r] = (bf16_t)pv;
+                // the 1/(1-p) of the dropout is applied once, to the finished row
+                pf[t >> 1][(t & 1) * 4 + r] = (bf16_t)(keep[r] ? pv : 0.f);
             }
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -198,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
                     frag_cols<HD>(Vl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
     }
     const float l = quad_sum(l_run);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? p.drop_scale / l : 0.f;
     if (qok) {
         bf16_t* orow = (bf16_t*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
 #pragma unroll
@@ -210,11 +261,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnArgs p) {
         }
         if (g == 0 && p.lse) p.lse[(long)bh * p.S + q] = m_run + __logf(l);
     }
+    }
 }
 
 // ================================================================== backward: dQ (query-major)
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
+// SEQ as in the forward: one workgroup of 8 waves per (sequence, head), K and V both in LDS.
+template <int HD, bool SEQ>
+__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dq_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -222,14 +275,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
     const int SP = (p.S + 63) & ~63;
     const int nthreads = blockDim.x;
     char* Kl = smem;
+    char* Vl = smem + SP * G::ROWB;                                   // SEQ only
     const bf16_t* vbase = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs;
     bf16x8 vf[4][G::KS];
-    frags_from_global<HD>(vbase, p.v_ss, 0, p.S, lane, vf);       // V is only a row-major operand here: no LDS copy
-    rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, nthreads);
+    if constexpr (!SEQ) frags_from_global<HD>(vbase, p.v_ss, 0, p.S, lane, vf);       // V is only a row-major operand here: no LDS copy
+    if constexpr (SEQ) rows_to_lds2<HD, 8>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, Vl, vbase, p.v_ss, 0, p.S, SP, tid, nthreads);
+    else rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, nthreads);
     __syncthreads();
-    const int qw = p.q_start + blockIdx.y * (nthreads >> 2) + wave * 16;
     const int qend = min(p.q_start + p.nq, p.S);
-    if (qw >= qend) return;
+    const int qstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);
+    for (int qw = p.q_start + (SEQ ? 0 : blockIdx.y * (nthreads >> 2)) + wave * 16; qw < qend; qw += qstep) {
     const int q = qw + i;
     const bool qok = q < qend;
     const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs + (long)q * p.q_ss;
@@ -245,18 +300,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum += (float)dof[ks][e] * (float)of[e];
     }
-    const float lse = qok ? p.lse[(long)bh * p.S + q] : 0.f;
+    const float nlse2 = qok ? -p.lse[(long)bh * p.S + q] * ATT_LOG2E : 0.f;
+    const int klim = qok ? key_limit(q, p.S, p.mask_mode, p.open_cols) : 0;
+    const int klim_wave = qw + 16 <= qend ? key_limit(qw, p.S, p.mask_mode, p.open_cols) : 0;     // 0: a partial tile always masks
     // delta = rowsum(dO * O): the four lanes (g) of a query hold disjoint quarters of its row
     const float delta = quad_sum(dsum);
     if (qok && g == 0) p.delta[(long)bh * p.S + q] = delta;       // the key-major kernel reads it
-    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S4);
     f32x4 acc[G::DT];
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
 
     for (int kb = 0; kb < SP; kb += 64) {
-        bf16x8 vn[4][G::KS];
-        if (kb + 64 < SP) frags_from_global<HD>(vbase, p.v_ss, kb + 64, p.S, lane, vn);      // next key block of V
         bf16x8 dsf[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -264,17 +319,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
+                if constexpr (SEQ) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Vl, kb + t * 16, ks * 32, lane), dof[ks], dp, 0, 0, 0);
+                else dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
             }
+            bool keep[4] = {true, true, true, true};
+            if (p.drop_thr) dropout_keep4(p.drop_k0, p.drop_k1, idx_row + kb + t * 16 + 4 * g, p.drop_thr, keep);
+            const bool masked = kb + 64 > klim_wave;          // wave-uniform: some query of the wave does not see the whole block
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kb + t * 16 + 4 * g + r;
-                const bool vis = qok && key_visible(q, key, p.S, p.mask_mode, p.open_cols);
-                const float pv = vis ? __expf(s[r] - lse) : 0.f;
-                float dpv = dp[r];
-                if (p.drop_thr) dpv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? dpv * p.drop_scale : 0.f;
+                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nlse2));
+                if (masked) pv = kb + t * 16 + 4 * g + r < klim ? pv : 0.f;
+                const float dpv = keep[r] ? dp[r] * p.drop_scale : 0.f;
                 dsf[t >> 1][(t & 1) * 4 + r] = (bf16_t)(pv * (dpv - delta));
             }
+        }
+        if constexpr (!SEQ) {
+            // the next key block of V replaces the fragments just consumed; the dS K products below cover the latency
+            if (kb + 64 < SP) frags_from_global<HD>(vbase, p.v_ss, kb + 64, p.S, lane, vf);
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -282,12 +343,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
             for (int dt = 0; dt < G::DT; ++dt)
                 acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
-        if (kb + 64 < SP) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks) vf[t][ks] = vn[t][ks];
-        }
     }
     if (qok) {
         bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
@@ -299,11 +354,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnArgs p) {
             *reinterpret_cast<bf16x4*>(dqrow + dt * 16 + 4 * g) = o;
         }
     }
+    }
 }
 
 // ================================================================== backward: dK, dV (key-major)
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
+// SEQ = true: one workgroup of 8 waves per (sequence, head) walks ALL key tiles (wave, wave + 8, ...), so Q and dO
+// are staged once per head instead of once per 64-key slab.
+template <int HD, bool SEQ>
+__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -314,15 +372,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
     char* Dl = smem + NQP * G::ROWB;
     float* lse_l = reinterpret_cast<float*>(smem + 2 * NQP * G::ROWB);
     float* del_l = lse_l + NQP;
-    rows_to_lds<HD>(Ql, (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs, p.q_ss, p.q_start, nq, NQP, tid, 256);
-    rows_to_lds<HD>(Dl, (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs, p.do_ss, p.q_start, nq, NQP, tid, 256);
-    for (int c = tid; c < NQP; c += 256) {
-        lse_l[c] = c < nq ? p.lse[(long)bh * p.S + p.q_start + c] : 0.f;
+    const int nthreads = blockDim.x;
+    rows_to_lds2<HD, SEQ ? 8 : 2>(Ql, (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs, p.q_ss, Dl, (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs, p.do_ss,
+                                  p.q_start, nq, NQP, tid, nthreads);
+    for (int c = tid; c < NQP; c += nthreads) {
+        lse_l[c] = c < nq ? -p.lse[(long)bh * p.S + p.q_start + c] * ATT_LOG2E : 0.f;      // kept as -lse * log2(e)
         del_l[c] = c < nq ? p.delta[(long)bh * p.S + p.q_start + c] : 0.f;
     }
     __syncthreads();
-    const int kw = blockIdx.y * 64 + wave * 16;
-    if (kw >= p.S) return;
+    const int kstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);
+    for (int kw = (SEQ ? 0 : blockIdx.y * 64) + wave * 16; kw < p.S; kw += kstep) {
     const int key = kw + i;
     const bool kok = key < p.S;
     const bf16_t* krow = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs + (long)key * p.k_ss;
@@ -336,9 +395,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
     f32x4 dkacc[G::DT], dvacc[G::DT];
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) { dkacc[dt] = f32x4{0, 0, 0, 0}; dvacc[dt] = f32x4{0, 0, 0, 0}; }
+    // this lane's key is seen by the local queries [qlo, qhi); a query block inside every lane's range needs no masking
+    const bool open_key = p.mask_mode == CAPDEC_MASK_NONE || key < p.open_cols;
+    const int qlo = open_key ? 0 : max(0, key - p.q_start);
+    const int qhi = kok ? nq : 0;
+    const bool open_tile = p.mask_mode == CAPDEC_MASK_NONE || kw + 15 < p.open_cols;
+    const int qlo_wave = open_tile ? 0 : max(0, kw + 15 - p.q_start);
+    const int qhi_wave = kw + 16 <= p.S ? nq : 0;
+    // dropout: the 4 lanes of an aligned quad hold 4 adjacent keys of the same 4 queries, i.e. the 4 fields of the
+    // same 4 hashes: each lane computes the hash of ONE query and the quad exchanges them
+    const uint32_t grp_key = (uint32_t)(key >> 2), grp_stride = (uint32_t)(p.S4 >> 2);
+    const uint32_t fsel = i & 3, fshift = (i & 1) * 16;
 
     for (int q0 = 0; q0 < NQP; q0 += 32) {
         bf16x8 pf, dsf;
+        const bool masked = q0 < qlo_wave || q0 + 32 > qhi_wave;        // wave-uniform
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 s = f32x4{0, 0, 0, 0}, dp = f32x4{0, 0, 0, 0};
@@ -347,20 +418,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Ql, q0 + t * 16, ks * 32, lane), kf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Dl, q0 + t * 16, ks * 32, lane), vf[ks], dp, 0, 0, 0);
             }
+            const int qb = q0 + t * 16 + 4 * g;                // first of the lane's 4 local query rows
+            const f32x4 nl2 = *reinterpret_cast<const f32x4*>(lse_l + qb), dl4 = *reinterpret_cast<const f32x4*>(del_l + qb);
+            DropBits hq;
+            hq.a = hq.b = 0xFFFFFFFFu;
+            if (p.drop_thr) hq = dropout_hash4(p.drop_k0, p.drop_k1, (uint32_t)(bh * p.S + p.q_start + qb + (int)fsel) * grp_stride + grp_key);
+            // the word holding field (key & 3) of the hash of query r, which quad lane r computed
+            const uint32_t hwa[4] = {quad_bcast<0>(hq.a), quad_bcast<1>(hq.a), quad_bcast<2>(hq.a), quad_bcast<3>(hq.a)};
+            const uint32_t hwb[4] = {quad_bcast<0>(hq.b), quad_bcast<1>(hq.b), quad_bcast<2>(hq.b), quad_bcast<3>(hq.b)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ql = q0 + t * 16 + 4 * g + r;       // local query row
-                const int qq = p.q_start + ql;
-                const bool vis = kok && ql < nq && key_visible(qq, key, p.S, p.mask_mode, p.open_cols);
-                const float pv = vis ? __expf(s[r] - lse_l[ql]) : 0.f;
-                float pd = pv, dpv = dp[r];
-                if (p.drop_thr) {
-                    const bool keep = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)((bh * p.S + qq) * (long)p.S) + key, p.drop_thr);
-                    pd = keep ? pv * p.drop_scale : 0.f;
-                    dpv = keep ? dpv * p.drop_scale : 0.f;
-                }
-                pf[t * 4 + r] = (bf16_t)pd;
-                dsf[t * 4 + r] = (bf16_t)(pv * (dpv - del_l[ql]));
+                const int ql = qb + r;
+                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nl2[r]));
+                if (masked) pv = (ql >= qlo && ql < qhi) ? pv : 0.f;
+                const bool keep = ((((fsel & 2) ? hwb[r] : hwa[r]) >> fshift) & 0xFFFFu) >= p.drop_thr;
+                pf[t * 4 + r] = (bf16_t)(keep ? pv : 0.f);                    // 1/(1-p) is applied to the finished dV
+                dsf[t * 4 + r] = (bf16_t)(pv * ((keep ? dp[r] * p.drop_scale : 0.f) - dl4[r]));
             }
         }
 #pragma unroll
@@ -376,10 +449,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnArgs p) {
         for (int dt = 0; dt < G::DT; ++dt) {
             bf16x4 a, c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dkacc[dt][r]; c[r] = (bf16_t)dvacc[dt][r]; }
+            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dkacc[dt][r]; c[r] = (bf16_t)(dvacc[dt][r] * p.drop_scale); }
             *reinterpret_cast<bf16x4*>(dkrow + dt * 16 + 4 * g) = a;
             *reinterpret_cast<bf16x4*>(dvrow + dt * 16 + 4 * g) = c;
         }
+    }
     }
 }
 
@@ -436,7 +510,7 @@ __global__ __launch_bounds__(64) void attn_fwd_simple(AttnArgs p) {
     }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S4);
     for (int key = lane; key < p.S; key += 64) {
         float pv = pr[key] * inv;
         if (p.drop_thr) pv = dropout_keep(p.drop_k0, p.drop_k1, idx_row + key, p.drop_thr) ? pv * p.drop_scale : 0.f;
@@ -468,7 +542,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_simple(AttnArgs p) {
     for (int j = lane; j < p.hd; j += 64) { qs[j] = to_f32<T>(qrow[j]); dos[j] = to_f32<T>(dorow[j]); }
     __syncthreads();
     const float lse = p.lse[(long)bh * p.S + q], delta = p.delta[(long)bh * p.S + q];
-    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S);
+    const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S4);
     for (int key = lane; key < p.S; key += 64) {
         float dsv = 0.f;
         if (key_visible(q, key, p.S, p.mask_mode, p.open_cols)) {
@@ -517,7 +591,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_simple(AttnArgs p) {
             const float pv = expf(s - p.lse[(long)bh * p.S + q]);
             pd = pv;
             if (p.drop_thr) {
-                const bool keep = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)((bh * p.S + q) * (long)p.S) + key, p.drop_thr);
+                const bool keep = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)((bh * p.S + q) * (long)p.S4) + key, p.drop_thr);
                 pd = keep ? pv * p.drop_scale : 0.f;
                 dp = keep ? dp * p.drop_scale : 0.f;
             }
@@ -620,7 +694,7 @@ int fill_args(const capdec_attn_desc* d, AttnArgs& a) {
     CAPDEC_CHECK(d->dtype == CAPDEC_BF16 || d->dtype == CAPDEC_F32, "attn: bad dtype");
     CAPDEC_CHECK(d->B > 0 && d->H > 0 && d->S > 0 && d->hd > 0, "attn: bad shape");
     CAPDEC_CHECK(d->q_start >= 0 && d->nq >= 0 && d->q_start + d->nq <= d->S, "attn: query range [%d,%d) outside sequence %d", d->q_start, d->q_start + d->nq, d->S);
-    CAPDEC_CHECK((long)d->B * d->H * d->S * d->S < (1L << 32) || d->drop.p <= 0.f, "attn: dropout index space exceeds 2^32");
+    CAPDEC_CHECK((long)d->B * d->H * d->S * ((d->S + 3) & ~3) < (1L << 32) || d->drop.p <= 0.f, "attn: dropout index space exceeds 2^32");
     memset(&a, 0, sizeof(a));
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o;
     a.q_bs = d->q_bs; a.q_hs = d->q_hs; a.q_ss = d->q_ss;
@@ -628,6 +702,7 @@ int fill_args(const capdec_attn_desc* d, AttnArgs& a) {
     a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_ss = d->v_ss;
     a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_ss = d->o_ss;
     a.B = d->B; a.H = d->H; a.S = d->S; a.hd = d->hd; a.q_start = d->q_start; a.nq = d->nq;
+    a.S4 = (d->S + 3) & ~3;
     a.mask_mode = d->mask_mode;
     a.open_cols = d->mask_mode == CAPDEC_MASK_REFERENCE ? 16 * 768 : (d->mask_mode == CAPDEC_MASK_PREFIX_CAUSAL ? d->prefix_len : 0);
     a.drop_thr = d->drop.p > 0.f ? dropout_threshold(d->drop.p) : 0u;
@@ -670,9 +745,15 @@ extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
         const int SP = (a.S + 63) & ~63;
         const int lds = SP * (a.hd * 2 + 16);
         CAPDEC_CHECK(lds <= 160 * 1024, "attn_fwd(bf16): sequence %d too long for the LDS-resident V design (hd=%d)", a.S, a.hd);
-        const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;        // a wave per 16 queries, at most 4 per workgroup
-        dim3 grid(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), block(64 * nwaves);
-        HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD>, lds); hipLaunchKernelGGL(attn_fwd_mfma<HD>, grid, block, lds, st, a));
+        if (a.nq > 64 && 2 * lds <= 160 * 1024) {
+            // long query range: one workgroup of 8 waves per (sequence, head), K and V both resident in LDS
+            HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, true>, 2 * lds);
+                        hipLaunchKernelGGL((attn_fwd_mfma<HD, true>), dim3(a.B * a.H), dim3(512), 2 * lds, st, a));
+        } else {
+            const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;        // a wave per 16 queries, at most 4 per workgroup
+            dim3 grid(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), block(64 * nwaves);
+            HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, false>, lds); hipLaunchKernelGGL((attn_fwd_mfma<HD, false>), grid, block, lds, st, a));
+        }
     } else {
         const int lds = (a.hd + a.S) * 4;
         dim3 grid(a.B * a.H, a.nq), block(64);
@@ -710,13 +791,22 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
         const int lds_k = 2 * NQP * (a.hd * 2 + 16) + 2 * NQP * 4;
         CAPDEC_CHECK(lds_q <= 160 * 1024 && lds_k <= 160 * 1024, "attn_bwd(bf16): sequence %d too long for the LDS-resident design (hd=%d)", a.S, a.hd);
         dim3 block(256);
-        if (a.nq > 0) {
+        if (a.nq > 64 && 2 * lds_q <= 160 * 1024) {
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, true>, 2 * lds_q);
+                        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, true>), dim3(a.B * a.H), dim3(512), 2 * lds_q, st, a));
+        } else if (a.nq > 0) {
             const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;
             dim3 gq(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), bq(64 * nwaves);
-            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD>, lds_q); hipLaunchKernelGGL(attn_bwd_dq_mfma<HD>, gq, bq, lds_q, st, a));
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false>, lds_q); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false>), gq, bq, lds_q, st, a));
         }
-        dim3 gk(a.B * a.H, (a.S + 63) / 64);
-        HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD>, lds_k); hipLaunchKernelGGL(attn_bwd_dkv_mfma<HD>, gk, block, lds_k, st, a));
+        if (a.nq > 64 && a.S > 128) {
+            // many queries staged per workgroup: stage them once per (sequence, head) and walk every key tile
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, true>, lds_k);
+                        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, true>), dim3(a.B * a.H), dim3(512), lds_k, st, a));
+        } else {
+            dim3 gk(a.B * a.H, (a.S + 63) / 64);
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, false>, lds_k); hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, false>), gk, block, lds_k, st, a));
+        }
     } else {
         if (a.nq > 0) {
             const int lds_q = (2 * a.hd + a.S) * 4;

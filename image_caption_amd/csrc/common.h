@@ -54,23 +54,40 @@ __device__ __forceinline__ void store_from_f32(void* p, long i, int dtype, float
 }
 
 // ---------------------------------------------------------------- dropout RNG
-// Counter-based: keep(idx) depends only on (key0, key1, idx), so the backward
-// pass regenerates the forward's mask from the same keys with no stored mask.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
+// Counter-based: keep(idx) depends only on (key0, key1, idx), so the backward pass regenerates the
+// forward's mask from the same keys with no stored mask.  One hash serves FOUR consecutive elements:
+// element idx takes the 16-bit field (idx & 3) of hash(key0, key1, idx >> 2) and is kept when that field
+// is >= thr16 = floor(p * 65536).  32-bit integer multiplies are quarter-rate instructions, so the hash
+// (one multiply-xorshift round, then two different multipliers for the two output words: four multiplies)
+// is shared by the four elements wherever a lane holds an aligned group of them.
+struct DropBits { uint32_t a, b; };    // fields 0,1 = low/high half of a; fields 2,3 = low/high half of b
+__device__ __forceinline__ DropBits dropout_hash4(uint32_t key0, uint32_t key1, uint32_t group) {
+    uint32_t x = (group ^ key1) * 0x9E3779B1U + key0;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
+    DropBits h;
+    h.a = x * 0x846ca68bU; h.a ^= h.a >> 16;
+    h.b = x * 0x9E485565U; h.b ^= h.b >> 16;
+    return h;
 }
-__device__ __forceinline__ uint32_t dropout_bits(uint32_t key0, uint32_t key1, uint32_t idx) {
-    return mix32(mix32(idx * 0x9E3779B1U + key0) ^ key1);
+__device__ __forceinline__ uint32_t dropout_field(DropBits h, uint32_t f) {
+    const uint32_t w = (f & 2) ? h.b : h.a;
+    return (f & 1) ? w >> 16 : w & 0xFFFFu;
 }
-// threshold = floor(p * 2^32); keep when bits >= threshold
+// any single element
 __device__ __forceinline__ bool dropout_keep(uint32_t key0, uint32_t key1, uint32_t idx, uint32_t thr) {
-    return dropout_bits(key0, key1, idx) >= thr;
+    return dropout_field(dropout_hash4(key0, key1, idx >> 2), idx & 3) >= thr;
 }
+// the four elements idx4 .. idx4+3, idx4 a multiple of 4
+__device__ __forceinline__ void dropout_keep4(uint32_t key0, uint32_t key1, uint32_t idx4, uint32_t thr, bool (&keep)[4]) {
+    const DropBits h = dropout_hash4(key0, key1, idx4 >> 2);
+    keep[0] = (h.a & 0xFFFFu) >= thr; keep[1] = (h.a >> 16) >= thr;
+    keep[2] = (h.b & 0xFFFFu) >= thr; keep[3] = (h.b >> 16) >= thr;
+}
+// thr16 of a probability p > 0 (at least 1, so that "dropout on" and thr != 0 stay equivalent)
 static inline uint32_t dropout_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    if (t <= 0) return 0;
-    if (t >= 4294967295.0) return 4294967295U;
+    double t = (double)p * 65536.0;
+    if (t < 1.0) return 1;
+    if (t >= 65535.0) return 65535U;
     return (uint32_t)t;
 }
 

@@ -234,6 +234,16 @@ __device__ __forceinline__ void store4_any(void* base, long idx, int dtype, bool
 // SIDE = false: no per-element side input (residual / gate / accumulate): the row loop
 // contains no global load, so its stores are never waited for.
 // SIDE = true: side inputs of 4 rows are fetched together, then the 4 rows are finished.
+// keep flags of the 4 consecutive elements idx .. idx+3: one hash when idx is a multiple of 4 (every lane's
+// column group is, when N is a multiple of 4), else one per element
+__device__ __forceinline__ void keep_flags4(uint32_t k0, uint32_t k1, uint32_t idx, uint32_t thr, bool (&keep)[4]) {
+    if ((idx & 3) == 0) dropout_keep4(k0, k1, idx, thr, keep);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = dropout_keep(k0, k1, idx + e, thr);
+    }
+}
+
 template <bool SIDE>
 __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
     const int c4 = (lane & 15) * 4, g = lane >> 4;
@@ -268,18 +278,21 @@ __device__ __forceinline__ void epilogue_std(const GemmArgs& p, const float* cs,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = (gat[e] != 0.f) ? x[e] * p.gate_scale : 0.f;
             } else if (p.gate_mode == CAPDEC_GATE_GELU_PRE) {
+                bool gkeep[4] = {true, true, true, true};
+                if (p.gate_thr) keep_flags4(p.gate_k0, p.gate_k1, (uint32_t)(m * p.N + n), p.gate_thr, gkeep);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float f = gelu_grad_f(gat[e]);
-                    if (p.gate_thr) f = dropout_keep(p.gate_k0, p.gate_k1, (uint32_t)(m * p.N + n + e), p.gate_thr) ? f * p.gate_scale : 0.f;
+                    if (p.gate_thr) f = gkeep[e] ? f * p.gate_scale : 0.f;
                     x[e] *= f;
                 }
             }
         }
         if (p.drop_thr) {
+            bool keep[4];
+            keep_flags4(p.drop_k0, p.drop_k1, (uint32_t)(m * p.N + n), p.drop_thr, keep);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                x[e] = dropout_keep(p.drop_k0, p.drop_k1, (uint32_t)(m * p.N + n + e), p.drop_thr) ? x[e] * p.drop_scale : 0.f;
+            for (int e = 0; e < 4; ++e) x[e] = keep[e] ? x[e] * p.drop_scale : 0.f;
         }
         if constexpr (SIDE) x += res + cin;
         float v[4], pv[4];
@@ -534,9 +547,14 @@ __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float
             for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(a[e] * sc[4 * q + e], relu_floor);
         }
         if (p.drop_thr) {
-            const uint32_t base = (uint32_t)(m * p.N + n);
+            const uint32_t base = (uint32_t)(m * p.N + n);          // a multiple of W: N and n are
 #pragma unroll
-            for (int e = 0; e < W; ++e) v[e] = dropout_keep(p.drop_k0, p.drop_k1, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+            for (int q = 0; q < W / 4; ++q) {
+                bool keep[4];
+                dropout_keep4(p.drop_k0, p.drop_k1, base + 4 * q, p.drop_thr, keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = keep[e] ? v[4 * q + e] * p.drop_scale : 0.f;
+            }
         }
         if constexpr (sizeof(TO) == 2) {
             bf16x8 o;
@@ -965,6 +983,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ launch
 unsigned long long* g_stamps = nullptr;
+constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256)
 
@@ -1001,7 +1020,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         }
         const long wide_tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
         // deep-K plain products: 256x256 tiles, one workgroup per CU, as soon as every CU gets one
-        if (EPI == EPI_STD && ring_ok && a.K >= 2048 && wide_tiles * split >= 256) kern = KERN_WIDE;
+        if (EPI == EPI_STD && ring_ok && a.K >= 2048 && wide_tiles * split >= WIDE_MIN_WGS) kern = KERN_WIDE;
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && EPI == EPI_STD) kern = KERN_WIDE;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
@@ -1344,9 +1363,12 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
         // tiles of the kernel that will run; the smallest such split, since every slab is written and re-read
         const bool ring_ok = (a.K % 32) == 0 || (a.a_kmajor && a.b_kmajor);
         const long wide = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        const long maxsp = nkt / 8 < 8 ? nkt / 8 : 8;
-        // 256x256 tiles (one workgroup per CU) when some split gives every CU one; else 256x128 / 128x128 tiles
-        const bool wide_possible = ring_ok && a.K >= 2048 && wide * maxsp >= 256;
+        // at most 32 slabs, each at least 8 k-tiles deep, as many as the workspace holds
+        const long slab_bytes = (long)a.M * a.N * 4;
+        long maxsp = nkt / 8 < 32 ? nkt / 8 : 32;
+        if (d->workspace_bytes / slab_bytes < maxsp) maxsp = d->workspace_bytes / slab_bytes;
+        // 256x256 tiles (one workgroup per CU) when some split gives (nearly) every CU one; else 256x128 / 128x128 tiles
+        const bool wide_possible = ring_ok && a.K >= 2048 && wide * maxsp >= WIDE_MIN_WGS;
         const bool tall_possible = !a.a_kmajor && a.K >= 512 && (a.K % 32) == 0;
         const long unit = wide_possible ? wide : (tall_possible ? (long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN) : tiles);
         const long resident = wide_possible ? 256 : 512;
@@ -1354,7 +1376,7 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
         double best = 0.0;
         for (long sp = 1; sp <= maxsp; ++sp) {
             const long n = unit * sp;
-            if (wide_possible && n < 256) continue;
+            if (wide_possible && n < WIDE_MIN_WGS) continue;
             const double eff = (double)n / (double)((n + resident - 1) / resident * resident);
             if (eff > best + 0.03) { best = eff; split = sp; }
         }

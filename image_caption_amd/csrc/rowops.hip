@@ -263,8 +263,15 @@ __global__ __launch_bounds__(256) void colsum_stripe_kernel(const TI* x, long M,
             else for (int e = 0; e < 4 && n + e < N; ++e) v[e] = to_f32<TI>(x[r * ldx + n + e]);
             if constexpr (DROP) {
                 if (thr) {
+                    const uint32_t base = (uint32_t)(r * N + n);
+                    bool keep[4];
+                    if ((base & 3) == 0) dropout_keep4(k0, k1, base, thr, keep);      // one hash for the lane's 4 columns
+                    else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(k0, k1, (uint32_t)(r * N + n + e), thr) ? v[e] * scale : 0.f;
+                        for (int e = 0; e < 4; ++e) keep[e] = dropout_keep(k0, k1, base + e, thr);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * scale : 0.f;
                 }
                 if (full) store4<TG>(g + r * N + n, v);
                 else for (int e = 0; e < 4 && n + e < N; ++e) g[r * N + n + e] = from_f32<TG>(v[e]);

@@ -455,7 +455,7 @@ class DecoderEngine:
         Mt = M - r0
         k_attn, k_r1, k_h, k_r2 = sv["keys"]
         G = lambda name: grads[block_key(i, name, nbk)]           # noqa: E731
-        skws = self.buf("splitk_ws", (8 * max(3 * d * d, d * ff) * 4,), torch.uint8, dev)
+        skws = self.buf("splitk_ws", (32 * max(3 * d * d, d * ff) * 4,), torch.uint8, dev)     # up to 32 f32 slabs of the largest weight
         csws = self.buf("colsum_ws", (max(ops.colsum_workspace(M, 3 * d), ops.colsum_workspace(Mt, 3 * d)),), torch.uint8, dev)
         G("linear1.bias").zero_()            # summed by atomics in a GEMM epilogue; the other bias gradients are overwritten
         # ---- MLP

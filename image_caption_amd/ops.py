@@ -37,6 +37,13 @@ def dropout_mask(d: Dropout, n: int, device) -> torch.Tensor:
     return out
 
 
+def attn_dropout_mask(d: Dropout, B: int, H: int, S: int, device) -> torch.Tensor:
+    """Keep-mask [B,H,S,S] of the attention probabilities: the kernels index a row of S keys with a stride of
+    S rounded up to a multiple of 4 (each lane's four keys then share one hash)."""
+    S4 = (S + 3) // 4 * 4
+    return dropout_mask(d, B * H * S * S4, device).reshape(B, H, S, S4)[..., :S]
+
+
 def concat_ln_fwd(img, sos, cap, gamma, beta, *, pos=None, eps=1e-5, x_out=None, x_row0=0, y_out=None, mean=None, rstd=None):
     require_cuda(img, sos, cap, pos, gamma, beta, x_out, y_out, mean, rstd)
     B, P, d = img.shape

@@ -43,7 +43,8 @@ const char* capdec_last_error(void);
 
 /* ------------------------------------------------------------------ dropout keys
  * Dropout masks are a pure function of (key0, key1, element index); the backward
- * entry points regenerate them from the same keys.  thr = floor(p * 2^32). */
+ * entry points regenerate them from the same keys.  An element is dropped when its
+ * 16-bit hash field is below floor(p * 65536): p is honoured to 1.5e-5. */
 typedef struct {
     float p;        /* 0 disables */
     uint32_t key0;
@@ -133,8 +134,9 @@ typedef struct {
     /* K/V-cache scatter (greedy decoding): columns >= kv_q (kv_q = 0 or kv_d; N = kv_q + 2*kv_d)
      * go to kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_q go to C. */
     void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;
-    /* optional scratch: with >= 8*M*N*4 bytes a plain bf16 product (no epilogue term) whose tile grid
-     * is too small to fill the GPU is split along K into f32 slabs and summed in a fixed order */
+    /* optional scratch: a plain bf16 product (no epilogue term) whose tile grid is too small to fill the
+     * GPU is split along K into as many f32 slabs of M*N*4 bytes as pay off and fit (at most 32) and
+     * summed in a fixed order */
     void* workspace; long workspace_bytes;
 } capdec_gemm_desc;
 
@@ -155,7 +157,7 @@ typedef struct {
     int B, H, S, hd;
     int q_start, nq;
     int mask_mode, prefix_len;
-    capdec_dropout drop;     /* on probabilities; index ((b*H+h)*S+q)*S+key */
+    capdec_dropout drop;     /* on probabilities; index ((b*H+h)*S+q)*S4+key, S4 = S rounded up to a multiple of 4 */
     float* lse;
 } capdec_attn_desc;
 

@@ -297,6 +297,25 @@ def test_concat_ln_fwd_bwd(ydt, d):
 
 
 # ---------------------------------------------------------------------------- attention
+def test_dropout_mask_statistics():
+    """The counter-based mask: drop rate p, the four 16-bit fields of one hash equally likely and uncorrelated,
+    no correlation along rows or columns of the shapes in use, different keys independent."""
+    n = 1 << 22
+    for p in (0.1, 0.5):
+        keep = ops.dropout_mask(ops.dropout_keys(42, 3, 7, p), n, DEV)
+        assert abs((1 - keep.mean().item()) - p) < 2e-3
+        for f in range(4):
+            assert abs((1 - keep[f::4].mean().item()) - p) < 3e-3
+        k = keep - keep.mean()
+        for lag in (1, 2, 3, 4, 229, 232, 768, 2048):
+            assert abs((k[:-lag] * k[lag:]).mean().item() / k.var().item()) < 5e-3, lag
+    a = ops.dropout_mask(ops.dropout_keys(42, 3, 7, 0.1), n, DEV)
+    for other in (ops.dropout_keys(42, 3, 8, 0.1), ops.dropout_keys(42, 4, 7, 0.1), ops.dropout_keys(43, 3, 7, 0.1)):
+        b = ops.dropout_mask(other, n, DEV)
+        assert abs(torch.corrcoef(torch.stack([a, b]))[0, 1].item()) < 5e-3
+    assert ops.dropout_mask(ops.dropout_keys(1, 1, 1, 0.0), 1024, DEV).min().item() == 1.0
+
+
 def torch_attention(qkv, B, H, S, hd, mask, keep, p):
     d = H * hd
     q, k, v = qkv.float().reshape(S, B, 3, H, hd).permute(2, 1, 3, 0, 4)       # [B,H,S,hd] each
@@ -334,7 +353,7 @@ def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
     d = H * hd
     qkv = rnd(S * B, 3 * d, dtype=dtype, scale=0.7, seed=30)
     drop = ops.dropout_keys(3, 1, 5, p=p)
-    keep = ops.dropout_mask(drop, B * H * S * S, DEV).reshape(B, H, S, S) if p > 0 else None
+    keep = ops.attn_dropout_mask(drop, B, H, S, DEV) if p > 0 else None
     o = torch.full((S * B, d), float("nan"), device=DEV, dtype=dtype)
     lse = torch.empty(B * H * S, device=DEV)
     ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, mask_mode=mode, prefix_len=prefix, drop=drop)
@@ -353,9 +372,10 @@ def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
-def test_attention_query_range(dtype, tol):
+@pytest.mark.parametrize("S,hd,nq", [(50, 32, 9), (150, 96, 100), (300, 96, 70)])      # the last two: the whole-sequence kernels
+def test_attention_query_range(dtype, tol, S, hd, nq):
     # only the last nq queries are computed (scored rows of the last block)
-    B, H, S, hd, nq = 2, 2, 50, 32, 9
+    B, H = 2, 2
     d = H * hd
     qkv = rnd(S * B, 3 * d, dtype=dtype, scale=0.7, seed=32)
     o = torch.zeros(S * B, d, device=DEV, dtype=dtype)

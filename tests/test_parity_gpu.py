@@ -207,7 +207,7 @@ def test_training_dropout_vs_oracle_with_same_masks(dtype):
     seed = model.options.dropout_seed
     S, B, d, ff, H = sh.S, sh.B, sh.d, sh.ff, sh.nhead
     keep = {
-        "attn": ops.dropout_mask(ops.dropout_keys(seed, 0, step, p), B * H * S * S, DEV).reshape(B, H, S, S).cpu(),
+        "attn": ops.attn_dropout_mask(ops.dropout_keys(seed, 0, step, p), B, H, S, DEV).cpu(),
         "resid1": ops.dropout_mask(ops.dropout_keys(seed, 1, step, p), S * B * d, DEV).reshape(S, B, d).cpu(),
         "hidden": ops.dropout_mask(ops.dropout_keys(seed, 2, step, p), S * B * ff, DEV).reshape(S, B, ff).cpu(),
         "resid2": ops.dropout_mask(ops.dropout_keys(seed, 3, step, p), S * B * d, DEV).reshape(S, B, d).cpu(),

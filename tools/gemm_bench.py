@@ -33,7 +33,7 @@ def main():
     g = torch.Generator(device=DEV).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=DEV, generator=g).to(BF)     # noqa: E731
     rows = []
-    skws = torch.empty(8 * 2304 * 768 * 4, dtype=torch.uint8, device=DEV)
+    skws = torch.empty(32 * 2304 * 768 * 4, dtype=torch.uint8, device=DEV)
 
     def add(name, flops, fn):
         ms = timeit(fn, reps)
@@ -111,6 +111,9 @@ def main():
     wvp[:V] = wv
     dWw = torch.empty(V, d, device=DEV)
     hws = torch.empty(8 * Mt * d * 4, dtype=torch.uint8, device=DEV)
+    M12 = 290 * 256
+    dqkv12, x12 = r(M12, 3 * d), r(M12, d)
+    gin12, gl2 = torch.empty(3 * d, d, device=DEV), torch.empty(d, ff, device=DEV)
     kcases = {
         "head dgrad slab 8192x768x8192 (B kmajor)": (2.0 * Mt * slab * d, lambda: ops.gemm(dl, wv[:slab], dH, b_kmajor=True)),
         "head dgrad 8192x768x50304 (B kmajor, split-K)": (2.0 * Mt * Vp * d, lambda: ops.gemm(dlw, wvp, dH, M=Mt, N=d, K=Vp, b_kmajor=True, workspace=hws)),
@@ -118,6 +121,11 @@ def main():
         "head wgrad 50260x768x8192 (A,B kmajor)": (2.0 * Mt * V * d, lambda: ops.gemm(dlw, x_t, dWw, M=V, N=d, K=Mt, a_kmajor=True, b_kmajor=True)),
         "dgrad KV 58624x768x1536 (B kmajor)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, w_kv, dh1, b_kmajor=True)),
         "wgrad KV 1536x768x58624 (A,B kmajor, split-K)": (2.0 * M * 2 * d * d, lambda: ops.gemm(dkv, x_all, gkv, a_kmajor=True, b_kmajor=True, workspace=skws)),
+        # all rows through a block (stacked blocks): S = 290, M = 74240
+        "wgrad in_proj 2304x768x74240 (split-K)": (2.0 * M12 * 3 * d * d, lambda: ops.gemm(dqkv12, x12, gin12, a_kmajor=True, b_kmajor=True, workspace=skws)),
+        "wgrad out_proj 768x768x74240 (split-K)": (2.0 * M12 * d * d, lambda: ops.gemm(dqkv12[:, :d], x12, gin12[:d], a_kmajor=True, b_kmajor=True, workspace=skws)),
+        "wgrad linear1 2048x768x74240 (split-K)": (2.0 * M12 * ff * d, lambda: ops.gemm(dqkv12[:, :ff], x12, gin12[:ff], a_kmajor=True, b_kmajor=True, workspace=skws)),
+        "wgrad linear2 768x2048x74240 (split-K)": (2.0 * M12 * ff * d, lambda: ops.gemm(x12, dqkv12[:, :ff], gl2, a_kmajor=True, b_kmajor=True, workspace=skws)),
     }
     print("reduction-major operands: register | ring128 | ring 256x128 | ring 256x256 | default")
     for name, (fl, fn) in kcases.items():
