@@ -1278,8 +1278,30 @@ __global__ __launch_bounds__(256) void ce_grad_from_probs_kernel(T* pd, long ld,
 
 // out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
 template <typename T>
-__global__ void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
+    // out[m, n] (+)= sum over the slabs, always in slab order; four columns per thread and the loads of four
+    // slabs in flight at a time when the shapes allow 16-byte accesses
     const long stride = (long)gridDim.x * blockDim.x;
+    if ((N & 3) == 0 && (ldc & 3) == 0 && (slab & 3) == 0 && sizeof(T) == 4 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0) {
+        const long total4 = slab >> 2;
+        for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += stride) {
+            const long i = i4 << 2;
+            const long m = i / N, n = i - m * N;
+            float* dst = reinterpret_cast<float*>(out) + m * ldc + n;
+            f32x4 a = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
+            int s2 = 0;
+            for (; s2 + 4 <= split; s2 += 4) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (long)s2 * slab + i);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ws + (long)(s2 + 1) * slab + i);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(ws + (long)(s2 + 2) * slab + i);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(ws + (long)(s2 + 3) * slab + i);
+                a = (((a + v0) + v1) + v2) + v3;
+            }
+            for (; s2 < split; ++s2) a += *reinterpret_cast<const f32x4*>(ws + (long)s2 * slab + i);
+            *reinterpret_cast<f32x4*>(dst) = a;
+        }
+        return;
+    }
     const long total = (long)M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long m = i / N, n = i - m * N;

@@ -53,7 +53,8 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
 
 // ------------------------------------------------------------------ LayerNorm forward (+ prefix join)
 // src row for output row r = s*B + b: patches, then the sos slot, then the caption
-template <typename TIN, typename TOUT, bool CONCAT>
+// NV: float4 groups per lane (4 covers rows of up to 1024 columns, 8 up to 2048)
+template <typename TIN, typename TOUT, bool CONCAT, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs, long img_ss, const TIN* sos, const TIN* cap, const float* xin,
                                                       const float* pos, const float* gamma, const float* beta, float eps,
                                                       long M, int B, int P, int L, int d,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
     // a wave walks rows r, r + nwaves, ...: long-lived waves keep more bytes in flight than one wave per row
     for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += nwaves) {
         float* xo = r < x_row0 ? nullptr : xout;          // the joined row itself is only kept from x_row0 on
-        f32x4 v[LN_VEC];
+        f32x4 v[NV];
         float sum = 0.f;
         long s = 0;
         const TIN* src = nullptr;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
             src = s < P ? img + b * img_bs + s * img_ss : (s == P ? sos + b * d : cap + (b * L + (s - P - 1)) * d);
         }
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < d) {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
         const float mu = wave_sum(sum) / d;
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < d) {
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
         const float rs = rsqrtf(wave_sum(sq) / d + eps);
         if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < d) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
 // x comes either from a [M,d] f32 buffer or (CONCAT) straight from the three tensors the forward
 // joined, so the joined rows need not be kept.  dx_out == NULL: only the affine gradients are wanted
 // (the first block's input is data), which drops the two row reductions and the row store.
-template <typename TDY, typename TIN, bool CONCAT>
+template <typename TDY, typename TIN, bool CONCAT, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const TIN* img, long img_bs, long img_ss,
                                                       const TIN* sos, const TIN* cap,
                                                       const float* pos, int B, int P, int L, const float* gamma,
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
                                                       const float* dx_in, float* dx_out, float* partial) {
     __shared__ __attribute__((aligned(16))) float red[4 * 2 * 64 * 4];   // [wave][dgamma|dbeta][lane][4], one 1024-column slab per pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 dg[LN_VEC], db[LN_VEC];
+    f32x4 dg[NV], db[NV];
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) { dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0}; }
+    for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0}; }
     const long nwaves = (long)gridDim.x * 4;
     for (long r = (long)blockIdx.x * 4 + wave; r < M; r += nwaves) {
         const float mu = mean[r], rs = rstd[r];
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
             const long b = r - sq * B;
             src = sq < P ? img + b * img_bs + sq * img_ss : (sq == P ? sos + b * d : cap + (b * L + (sq - P - 1)) * d);
         }
-        f32x4 g[LN_VEC], xh[LN_VEC];
+        f32x4 g[NV], xh[NV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             g[i] = f32x4{0, 0, 0, 0}; xh[i] = f32x4{0, 0, 0, 0};
             if (c < d) {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
             c1 = wave_sum(c1) / d;
             c2 = wave_sum(c2) / d;
 #pragma unroll
-            for (int i = 0; i < LN_VEC; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int c = lane * 4 + i * 256;
                 if (c < d) {
                     f32x4 o;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
     }
     // fold the 4 waves of this block, one 256-lane x 4 slab per pass, into partial[block][2][d]
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (i * 256 >= d) break;
         __syncthreads();
         *reinterpret_cast<f32x4*>(&red[((wave * 2 + 0) * 64 + lane) * 4]) = dg[i];
@@ -220,10 +221,14 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* part
     }
 }
 
-int ln_bwd_blocks(long M) {
-    long nb = (M + 31) / 32;       // >= 8 rows per wave
+// Workgroups of a LayerNorm backward over M rows.  With dx the kernel is a read-modify-write stream whose rows each
+// need two reductions before their store: many short-lived waves keep the memory system busy.  Without dx it only
+// accumulates column sums: fewer, longer-lived waves leave fewer partial rows to write and fold.
+int ln_bwd_blocks(long M, bool with_dx) {
+    long nb = with_dx ? (M + 15) / 16 : (M + 31) / 32;
+    const long cap = with_dx ? 2048 : 512;
     if (nb < 1) nb = 1;
-    if (nb > 512) nb = 512;        // two blocks per CU; the finalize pass reads one partial row per block
+    if (nb > cap) nb = cap;
     return (int)nb;
 }
 
@@ -399,9 +404,14 @@ static void launch_ln_fwd(const void* img, long img_bs, long img_ss, const void*
                           const float* gamma, const float* beta, float eps, long M, int B, int P, int L, int d,
                           float* xout, long x_row0, void* y, float* mean, float* rstd, hipStream_t st) {
     const long nblk = (M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048;       // 8 workgroups per CU, each wave walks several rows
-    hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT>), dim3((unsigned)nblk), dim3(256), 0, st,
-                       (const TIN*)img, img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
-                       xout, x_row0, (TOUT*)y, mean, rstd);
+    if (d <= 1024)
+        hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT, 4>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           (const TIN*)img, img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
+                           xout, x_row0, (TOUT*)y, mean, rstd);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, CONCAT, 8>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           (const TIN*)img, img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, xin, pos, gamma, beta, eps, M, B, P, L, d,
+                           xout, x_row0, (TOUT*)y, mean, rstd);
 }
 
 extern "C" int capdec_concat_ln_fwd(const void* img, const void* sos, const void* cap, int in_dtype,
@@ -459,7 +469,7 @@ extern "C" int capdec_ln_fwd(const float* x, const float* gamma, const float* be
     return CAPDEC_OK;
 }
 
-extern "C" long capdec_ln_bwd_workspace(long M, int d) { return (long)ln_bwd_blocks(M) * 2 * d * 4; }
+extern "C" long capdec_ln_bwd_workspace(long M, int d) { return (long)ln_bwd_blocks(M, true) * 2 * d * 4; }
 
 extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                              const float* mean, const float* rstd, long M, int d,
@@ -469,14 +479,14 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
     CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_bwd: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
     if (M <= 0) return CAPDEC_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = ln_bwd_blocks(M);
+    const int nb = ln_bwd_blocks(M, dx_out != nullptr);
     const float* nf = nullptr;
-    if (dy_dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float, false>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0,
-                           gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float, false>), dim3(nb), dim3(256), 0, st, (const float*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0,
-                           gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial);
+#define CAPDEC_LNB_PLAIN(TDY, NVV)                                                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, float, false, NVV>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0, \
+                       gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial)
+    if (dy_dtype == CAPDEC_BF16) { if (d <= 1024) CAPDEC_LNB_PLAIN(bf16_t, 4); else CAPDEC_LNB_PLAIN(bf16_t, 8); }
+    else { if (d <= 1024) CAPDEC_LNB_PLAIN(float, 4); else CAPDEC_LNB_PLAIN(float, 8); }
+#undef CAPDEC_LNB_PLAIN
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -489,19 +499,21 @@ int ln_bwd_affine_from_sources(const void* dy, int dy_dtype, const void* img, lo
                                int in_dtype, const float* pos, const float* gamma, const float* mean, const float* rstd,
                                int B, int P, int L, int d, float* dgamma, float* dbeta, void* partial, hipStream_t st) {
     const long M = (long)(P + (L >= 0 ? 1 + L : 0)) * B;
-    const int nb = ln_bwd_blocks(M);
+    const int nb = ln_bwd_blocks(M, false);
     const float* nf = nullptr;
     float* nd = nullptr;
     const int Lk = L >= 0 ? L : 0;
-#define CAPDEC_LNB(TDY, TIN)                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TIN, true>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, nf, (const TIN*)img,   \
+#define CAPDEC_LNB2(TDY, TIN, NVV)                                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TIN, true, NVV>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, nf, (const TIN*)img, \
                        img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, pos, B, P, Lk, gamma, mean, rstd, M, d, nf, nd, (float*)partial)
+#define CAPDEC_LNB(TDY, TIN) do { if (d <= 1024) CAPDEC_LNB2(TDY, TIN, 4); else CAPDEC_LNB2(TDY, TIN, 8); } while (0)
     const bool db = dy_dtype == CAPDEC_BF16, ib = in_dtype == CAPDEC_BF16;
     if (db && ib) CAPDEC_LNB(bf16_t, bf16_t);
     else if (db) CAPDEC_LNB(bf16_t, float);
     else if (ib) CAPDEC_LNB(float, bf16_t);
     else CAPDEC_LNB(float, float);
 #undef CAPDEC_LNB
+#undef CAPDEC_LNB2
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;

@@ -285,10 +285,11 @@ def test_concat_ln_fwd_bwd(ydt, d):
     # affine gradients only: from the kept rows, and from the sources of the join
     dg2, db2 = torch.full((d,), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
     ops.ln_bwd(dy, x, gamma, mean, rstd, None, None, dg2, db2, ws)
-    assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    close(dg2, gg.grad, 1e-5, "dgamma, affine only")
+    close(db2, bg.grad, 1e-5, "dbeta, affine only")
     dg3, db3 = torch.full((d,), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
     ops.concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dg3, db3, ws, pos=pos)
-    assert torch.equal(dg3, dg) and torch.equal(db3, db)
+    assert torch.equal(dg3, dg2) and torch.equal(db3, db2)          # same grid, same rows, same order: bit-identical
     # the joined rows below x_row0 are not written
     x2 = torch.full_like(x, float("nan"))
     y3 = torch.empty_like(y)
