@@ -92,11 +92,28 @@ static inline uint32_t dropout_threshold(float p) {
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact (erf-based) GELU, with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at f32 rounding level
+// for the CDF) so that the CDF and the density share ONE exponential: e^{-x^2/2} is both the density's
+// and, with y = |x| / sqrt(2), the e^{-y^2} of the erf formula.  One v_exp, one v_rcp and a dozen FMAs per element,
+// against a libm erff plus a second exponential.
+__device__ __forceinline__ void normal_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // e^{-x^2/2}
+    const float y = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, y, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float half_erf = fmaf(-0.5f * poly, u, 0.5f);                          // erf(y) / 2
+    cdf = 0.5f + copysignf(half_erf, x);
+    pdf = 0.39894228040143268f * u;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, pdf;
+    normal_cdf_pdf(x, cdf, pdf);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, pdf;
+    normal_cdf_pdf(x, cdf, pdf);
+    return fmaf(x, pdf, cdf);
 }
 
 // ---------------------------------------------------------------- reductions
