@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--greedy-only", action="store_true", help="skip the training benchmark (profiling of the decoding path)")
     ap.add_argument("--greedy-images", type=int, default=4096)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="weight-gradient products on the compute stream (A/B of the second stream)")
     ap.add_argument("--vocab-slab", type=int, default=0, help="vocabulary columns per backward slab (0: engine default)")
     return ap.parse_args()
 
@@ -140,6 +141,8 @@ def main():
                          scored_rows_only=not args.all_rows)
     if args.vocab_slab:
         opts.vocab_slab = args.vocab_slab
+    if args.no_wgrad_stream:
+        opts.wgrad_stream = False
     torch.manual_seed(42)                                           # config.py:27,41
     model = TransformerDecoder(768, 8, 6, 2048, 0.1, 50260, n_blocks=args.n_blocks, options=opts).to(dev)
     model.train()                                                   # decoder.py:144: dropout active

@@ -567,6 +567,71 @@ __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float
     }
 }
 
+// The backward product through activation + dropout (dz = (dy W) * act'(z) * keep / (1-p)) when nothing else is
+// asked for: 8 bf16 columns per lane, the gate tensor read and the result written 16 bytes at a time, all eight
+// gate loads of the lane in flight before the first use.  The host selects it (fast_epi == 16) when out and gate
+// are bf16 and N, ldc, ldg and both bases keep every lane's 8 columns aligned and inside N.
+__device__ __forceinline__ void epilogue_gate_fast(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
+    constexpr int W = 8, LPR = 64 / W, RPI = 64 / LPR;
+    const int c = (lane % LPR) * W, g = lane / LPR;
+    const int n = nw + c;
+    if (n >= p.N) return;
+    const bf16_t* gate = (const bf16_t*)p.gate;
+    bf16_t* C = (bf16_t*)p.C;
+    float csum[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) csum[e] = 0.f;
+    bf16x8 gv[64 / RPI];
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const long m = (long)mw + it * RPI + g;
+        gv[it] = m < p.M ? *reinterpret_cast<const bf16x8*>(gate + m * p.ldg + n) : bf16x8{};
+    }
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + g;
+        const long m = (long)mw + row;
+        if (m >= p.M) continue;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c), a1 = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c + 4);
+        float v[W] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (p.gate_mode == CAPDEC_GATE_RELU_OUT) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = (float)gv[it][e] != 0.f ? v[e] * p.gate_scale : 0.f;
+        } else {
+            bool keep[W] = {true, true, true, true, true, true, true, true};
+            if (p.gate_thr) {
+                const uint32_t base = (uint32_t)(m * p.N + n);          // a multiple of 8
+                bool k0[4], k1[4];
+                dropout_keep4(p.gate_k0, p.gate_k1, base, p.gate_thr, k0);
+                dropout_keep4(p.gate_k0, p.gate_k1, base + 4, p.gate_thr, k1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { keep[e] = k0[e]; keep[4 + e] = k1[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = keep[e] ? v[e] * (gelu_grad_f((float)gv[it][e]) * p.gate_scale) : 0.f;
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) { o[e] = (bf16_t)v[e]; csum[e] += v[e]; }
+        *reinterpret_cast<bf16x8*>(C + m * p.ldc + n) = o;
+    }
+    if (p.colpart) {
+        // column sums of this wave's 64 rows -> one row of the partial buffer, folded later in a fixed order
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float t = csum[e];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            csum[e] = t;
+        }
+        if (lane < LPR && mw < p.M) {
+            float* dst = p.colpart + (long)(mw >> 6) * p.ld_colpart + n;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
+        }
+    }
+}
+
 // The MFMAs are issued with the operands swapped (B fragment first), so that a lane holds
 //   C[row = lane & 15][cols 4*(lane>>4) .. +3]   of each 16x16 tile:
 // four CONSECUTIVE columns of one row, which go to the row-major LDS tile as one 16-byte write.
@@ -608,7 +673,10 @@ __device__ __forceinline__ void run_epilogue_at(const GemmArgs& p, float* cs, in
         if (p.fast_epi == 8) epilogue_std_fast<8, bf16_t>(p, cs, mw, nw, lane);
         else if (p.fast_epi == 4) epilogue_std_fast<4, float>(p, cs, mw, nw, lane);
         else epilogue_std<false>(p, cs, mw, nw, lane);
-    } else if constexpr (EPI == EPI_STD_SIDE) epilogue_std<true>(p, cs, mw, nw, lane);
+    } else if constexpr (EPI == EPI_STD_SIDE) {
+        if (p.fast_epi == 16) epilogue_gate_fast(p, cs, mw, nw, lane);
+        else epilogue_std<true>(p, cs, mw, nw, lane);
+    }
     else if constexpr (EPI == EPI_CE_FWD) {
         if (p.fast_epi == 8) epilogue_ce_fwd<8, bf16_t>(p, cs, mw, nw, slot, lane);
         else if (p.out_dtype == CAPDEC_BF16) epilogue_ce_fwd<4, bf16_t>(p, cs, mw, nw, slot, lane);
@@ -1158,7 +1226,7 @@ uint32_t keyed_thr(const capdec_dropout& d) { return d.p > 0.f ? dropout_thresho
 // bias gradient of one vocabulary slab: dbias[n] = sum over 64-row groups of the partial column sums.
 // A block owns 64 columns; its 16 row groups each add every 16th partial row (4 rows in flight per
 // thread), and the 16 partial results are added in a fixed order (deterministic).
-__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* part, int nrows, long ld, int nv, float* out) {
+__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* part, int nrows, long ld, int nv, float* out, int accumulate) {
     __shared__ float sh[16][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -1179,7 +1247,7 @@ __global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* part,
         float a = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) a += sh[i][c];
-        out[n] = a;
+        out[n] = accumulate ? out[n] + a : a;
     }
 }
 
@@ -1426,6 +1494,24 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
         if (a.out_dtype == CAPDEC_BF16 && (a.N % 8) == 0 && (a.ldc % 8) == 0) a.fast_epi = 8;
         else if (a.out_dtype == CAPDEC_F32 && (a.N % 4) == 0 && (a.ldc % 4) == 0) a.fast_epi = 4;
     }
+    // gate-only epilogue (the dgrad through activation + dropout) with 16-byte accesses
+    // (column sums then go through the workspace: one partial row per 64 rows, folded in a fixed order)
+    const long colpart_bytes = (long)((a.M + 63) / 64) * a.N * 4;
+    if (a.gate_mode != CAPDEC_GATE_NONE && !a.residual && !a.accumulate && a.col_scale_n == 0 && a.act == CAPDEC_ACT_NONE && !a.drop_thr &&
+        !a.aux_out && !a.kv_cache && a.out_dtype == CAPDEC_BF16 && a.gate_dtype == CAPDEC_BF16 &&
+        (a.N % 8) == 0 && (a.ldc % 8) == 0 && (a.ldg % 8) == 0 && aligned16(a.C) && aligned16(a.gate) &&
+        (!a.colsum || (d->workspace && aligned16(d->workspace) && d->workspace_bytes >= colpart_bytes))) {
+        a.fast_epi = 16;
+        if (a.colsum) {
+            a.colpart = (float*)d->workspace; a.ld_colpart = a.N; a.colsum = nullptr;
+            int rc = launch_gemm<EPI_STD_SIDE>(a, d->in_dtype, (hipStream_t)stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(colpart_reduce_kernel, dim3((a.N + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+                               (const float*)d->workspace, (int)((a.M + 63) / 64), (long)a.N, a.N, d->colsum, 1);
+            CAPDEC_LAUNCH_CHECK();
+            return CAPDEC_OK;
+        }
+    }
     if (a.residual || a.accumulate || a.gate_mode != CAPDEC_GATE_NONE) return launch_gemm<EPI_STD_SIDE>(a, d->in_dtype, (hipStream_t)stream);
     return launch_gemm<EPI_STD>(a, d->in_dtype, (hipStream_t)stream);
 }
@@ -1537,7 +1623,7 @@ extern "C" int capdec_logits_ce_bwd_from_probs(void* probs_dl, int dtype, long M
     else
         hipLaunchKernelGGL(ce_grad_from_probs_kernel<float>, grid, block, 0, st, (float*)probs_dl, ld, M, ws.part4, ws.np, lse, labels, B, L, gscale, part, ldp);
     if (dbias)
-        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((V + 63) / 64), dim3(1024), 0, st, (const float*)part, (int)((M + 63) / 64), ldp, V, dbias);
+        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((V + 63) / 64), dim3(1024), 0, st, (const float*)part, (int)((M + 63) / 64), ldp, V, dbias, 0);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -1572,7 +1658,7 @@ extern "C" int capdec_logits_ce_bwd_slab(const void* h, const void* W, const flo
     int rc = launch_gemm<EPI_CE_BWD>(a, dtype, (hipStream_t)stream);
     if (rc || !dbias) return rc;
     hipLaunchKernelGGL(colpart_reduce_kernel, dim3((nv + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
-                       (const float*)workspace, (int)((M + 63) / 64), ldp, nv, dbias + v0);
+                       (const float*)workspace, (int)((M + 63) / 64), ldp, nv, dbias + v0, 0);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -463,12 +463,13 @@ class DecoderEngine:
         ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
         self._on_side_stream(lambda: ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
+        gcws = self.buf("gate_colsum_ws", ((Mt + 63) // 64 * ff * 4,), torch.uint8, dev)     # one partial row of bias sums per 64 rows
         if self.opt.activation == "relu":
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
-                     gate_drop=k_h, colsum=G("linear1.bias"))
+                     gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
         else:
             ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
-                     gate_drop=k_h, colsum=G("linear1.bias"))
+                     gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
         self._on_side_stream(lambda: ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dh2 = self.buf("dh", (Mt, d), cdt, dev)
         ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)

@@ -130,7 +130,8 @@ typedef struct {
      *  GELU_PRE: gate tensor = saved pre-activation z; factor = gelu'(z) * keep / (1 - p) */
     const void* gate; long ldg; int gate_mode; int gate_dtype; capdec_dropout gate_drop;
     void* aux_out; long ldaux;   /* out_dtype, NULL = off */
-    float* colsum;               /* [N] f32 atomically += column sums of the stored values */
+    float* colsum;               /* [N] f32 += column sums of the stored values (atomic adds; with a gate-only bf16
+                                  * epilogue and a workspace of ceil(M/64)*N*4 bytes: a deterministic two-stage sum) */
     /* K/V-cache scatter (greedy decoding): columns >= kv_q (kv_q = 0 or kv_d; N = kv_q + 2*kv_d)
      * go to kv_cache[b][h][k|v][kv_s0 + s][j], row m = s*kv_B + b; columns < kv_q go to C. */
     void* kv_cache; int kv_q, kv_d, kv_B, kv_H, kv_hd, kv_smax, kv_s0;

@@ -225,6 +225,23 @@ def test_gemm_gates(dtype, tol):
     torch.nn.functional.gelu(zf).sum().backward()
     ref = (A.float() @ B.float()) * zf.grad * keep / 0.9
     close(out, ref, tol, "gelu gate")
+    # column sums of the gated product (the bias gradient): atomic adds, or -- with a workspace of one partial row
+    # per 64 rows -- a fixed-order two-stage sum; both accumulate into what the buffer holds
+    for mode, gate, gdrop, want in ((_lib.GATE_RELU_OUT, saved, _lib.Dropout(0.2, 0, 0), (A.float() @ B.float()) * (saved.float() != 0) / 0.8),
+                                    (_lib.GATE_GELU_PRE, z, gd, ref)):
+        cs_a = torch.full((N,), 0.5, device=DEV)
+        ops.gemm(A, B, out, b_kmajor=True, gate=gate, gate_mode=mode, gate_drop=gdrop, colsum=cs_a)
+        ws = torch.empty((M + 63) // 64 * N * 4, dtype=torch.uint8, device=DEV)
+        runs = []
+        for _ in range(2):
+            cs_w = torch.full((N,), 0.5, device=DEV)
+            ops.gemm(A, B, out, b_kmajor=True, gate=gate, gate_mode=mode, gate_drop=gdrop, colsum=cs_w, workspace=ws)
+            runs.append(cs_w)
+        close(out, want, tol, "gated product with column sums")
+        close(cs_a, want.sum(0) + 0.5, tol * 4, "column sums (atomic)")
+        close(runs[0], want.sum(0) + 0.5, tol * 4, "column sums (two-stage)")
+        if dtype == torch.bfloat16:                                   # the two-stage path exists for bf16 output and gate
+            assert torch.equal(runs[0], runs[1])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
