@@ -520,8 +520,8 @@ __device__ __forceinline__ void epilogue_ce_bwd(const GemmArgs& p, float* cs, in
     }
 }
 
-// The common forward epilogue, straight-line: (acc + bias) * column scale, ReLU, dropout, one 16-byte
-// store per row and lane (W = 8 bf16 or 4 f32 columns).  The host selects it when nothing else is asked
+// The common forward epilogue, straight-line: (acc + bias) * column scale, [pre-activation copy], ReLU / GELU, dropout,
+// one 16-byte store per row and lane (W = 8 bf16 or 4 f32 columns).  The host selects it when nothing else is asked
 // for and N, ldc and the base of C keep every lane's W columns aligned and either all inside N or all outside.
 template <int W, typename TO>
 __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float* cs, int mw, int nw, int lane) {
@@ -544,7 +544,25 @@ __device__ __forceinline__ void epilogue_std_fast(const GemmArgs& p, const float
         for (int q = 0; q < W / 4; ++q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * CS_LD + c + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(a[e] * sc[4 * q + e], relu_floor);
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e] * sc[4 * q + e];
+        }
+        if (p.aux_out) {                     // the pre-activation values, kept for the backward of the activation
+            TO* X = (TO*)p.aux_out;
+            if constexpr (sizeof(TO) == 2) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x8*>(X + m * p.ldaux + n) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(X + m * p.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        if (p.act == CAPDEC_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = gelu_f(v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], relu_floor);
         }
         if (p.drop_thr) {
             const uint32_t base = (uint32_t)(m * p.N + n);          // a multiple of W: N and n are
@@ -1489,10 +1507,10 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     }
     // straight-line epilogue: bias / column scale / ReLU / dropout only, every lane's 16-byte group of columns
     // aligned and entirely inside or outside N
-    if (!a.residual && !a.accumulate && a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache &&
-        a.act != CAPDEC_ACT_GELU && aligned16(a.C)) {
-        if (a.out_dtype == CAPDEC_BF16 && (a.N % 8) == 0 && (a.ldc % 8) == 0) a.fast_epi = 8;
-        else if (a.out_dtype == CAPDEC_F32 && (a.N % 4) == 0 && (a.ldc % 4) == 0) a.fast_epi = 4;
+    if (!a.residual && !a.accumulate && a.gate_mode == CAPDEC_GATE_NONE && !a.colsum && !a.kv_cache && aligned16(a.C) &&
+        (!a.aux_out || aligned16(a.aux_out))) {
+        const int w = a.out_dtype == CAPDEC_BF16 ? 8 : 4;
+        if ((a.N % w) == 0 && (a.ldc % w) == 0 && (!a.aux_out || (a.ldaux % w) == 0)) a.fast_epi = w;
     }
     // gate-only epilogue (the dgrad through activation + dropout) with 16-byte accesses
     // (column sums then go through the workspace: one partial row per 64 rows, folded in a fixed order)
