@@ -1000,6 +1000,186 @@ __global__ __launch_bounds__(64 * WM * WN, (DmaGeo<WM, WN, TI, NST>::WG_PER_CU))
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 
+// ------------------------------------------------------------------ bf16 MFMA kernel, 4 waves of 128x128
+// The ring kernels above read 12 KiB of fragments per wave and 32-deep step for 32 MFMAs; with the stage refills
+// (which also go through the LDS ports) two co-resident 256x128 workgroups or one 8-wave 256x256 workgroup move
+// ~144 KiB through the LDS per 1024 MFMA cycles of the CU -- more than its 128 B/clk carry.  Here a wave owns a
+// 128x128 block of a 256x256 tile: 16 KiB of fragments for 64 MFMAs, 96 KiB per 1024 MFMA cycles with the refills.
+// The 256 accumulator registers leave room for ONE wave per SIMD, so nothing else covers the LDS latency: the
+// fragments are double-buffered in registers -- those of step k+1 are read (and the ring refilled) between the
+// MFMA rows of step k -- and the ring holds NST = 4 stages, all in flight or being read.  Plain products only
+// (EPI_STD, incl. split-K slabs); K as for the ring kernels.
+// Transposing fragment read that the compiler cannot see into.  It makes every LDS read it cannot prove independent
+// of the LDS-DMA writes wait for ALL of them (s_waitcnt vmcnt(0)), and the transposing-read builtin carries nothing to
+// prove it with -- which empties the ring at every step.  As inline assembly the two reads are just instructions:
+// no wait is inserted, and none for their results either, so the caller waits (lgkmcnt) before it uses them.
+// `addr` = LDS byte address of the lane's first 8 bytes (image base + tr_lane_offset).
+__device__ __forceinline__ int tr_lane_offset(int rb, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int col = rb + 4 * pp;
+    return lds_off_kmajor(8 * g + q, col >> 3) + ((col & 7) << 1);
+}
+__device__ __forceinline__ bf16x8 read_frag_tr_opaque(unsigned addr) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr));
+    return __builtin_bit_cast(bf16x8, (u32x4{lo[0], lo[1], hi[0], hi[1]}));
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(const char, p); }
+
+// acc += a x b with the accumulator tied in place in the accumulation registers.  Left to the register allocator, a
+// kernel whose accumulators fill all 256 of them gets three-address MFMAs fed through copies.  Being opaque to the
+// compiler, it gets no hazard padding: the caller keeps dependent uses (the same accumulator, reads of the result) far away.
+__device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(__builtin_bit_cast(u32x4, a)), "v"(__builtin_bit_cast(u32x4, b)));
+}
+
+constexpr int QNST = 4, QSTAGE = 32768, QPIECES = 4;     // 16 KiB A image + 16 KiB B image per stage; 4 + 4 DMA pieces per wave
+constexpr int QLDS = QNST * QSTAGE;
+
+template <bool A_TR, bool B_TR>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    int tile_m, tile_n;
+    map_tile(tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    OperandView va, vb;
+    if (A_TR) { va.base = (const bf16_t*)p.A + m0; va.remaining = (long)p.K * p.lda - m0; }
+    else      { va.base = (const bf16_t*)p.A + (long)m0 * p.lda; va.remaining = (long)(p.M - m0) * p.lda; }
+    va.ld = p.lda; va.rows_left = p.M - m0;
+    if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
+    else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
+    vb.ld = p.ldb; vb.rows_left = p.N - n0;
+    unsigned offa[QPIECES], offb[QPIECES];
+#pragma unroll
+    for (int j = 0; j < QPIECES; ++j) {
+        offa[j] = dma_src_offset<A_TR>(va, 4 * j + wave, lane);
+        offb[j] = dma_src_offset<B_TR>(vb, 4 * j + wave, lane);
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (p.K + DBK - 1) / DBK;
+    int kt0 = 0, nk = nk_total;
+    if (p.split_k > 1) {
+        const int kper = (nk_total + p.split_k - 1) / p.split_k;
+        kt0 = blockIdx.y * kper;
+        nk = max(0, min(kper, nk_total - kt0));
+        p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
+    }
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+    // all NST stages go out at once; a stage index past the last k-tile still issues its (harmless) loads, so that the
+    // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
+#pragma unroll
+    for (int s = 0; s < QNST; ++s) {
+        dma_tile<A_TR, QPIECES, 4>(va, offa, (kt0 + s) * DBK, smem + s * QSTAGE, wave);
+        dma_tile<B_TR, QPIECES, 4>(vb, offb, (kt0 + s) * DBK, smem + s * QSTAGE + 16384, wave);
+    }
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+
+    // B fragments are double-buffered (every MFMA row of a step uses all eight); an A fragment is dead once its row of
+    // MFMAs has been issued, so the next step's takes its place while the following row runs (the last one goes
+    // through a spare register), which puts every LDS read at least one MFMA row before the end of the step.
+    bf16x8 fa[8], fb[2][8], fa7;
+    int troff[(A_TR || B_TR) ? 8 : 1];       // lane offsets of the eight 16-row fragments inside a reduction-major sub-image
+    if constexpr (A_TR || B_TR) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) troff[i] = tr_lane_offset(i * 16, lane);
+    }
+    auto read_a = [&](const char* sA, int i) {
+        if constexpr (A_TR) return read_frag_tr_opaque(lds_addr(sA + wr * DTILE_BYTES) + troff[i]);
+        else return dread_frag<false>(sA, wr * 128 + i * 16, lane);
+    };
+    auto read_b = [&](const char* sB, int i) {
+        if constexpr (B_TR) return read_frag_tr_opaque(lds_addr(sB + wc * DTILE_BYTES) + troff[i]);
+        else return dread_frag<false>(sB, wc * 128 + i * 16, lane);
+    };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QNST - 1) * 2 * QPIECES) : "memory");
+    __builtin_amdgcn_s_barrier();            // stage 0 has landed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa[i] = read_a(smem, i);
+        fb[0][i] = read_b(smem + 16384, i);
+    }
+    int slot = 0;                            // ring slot of stage kt
+    // One step: MFMAs on the fragments of stage kt (B: cb; last A: ca7, the others fa[0..6]) while those of stage kt+1 are
+    // read (B: nb; last A: na7) and the slot stage kt occupied is refilled with stage kt+NST.  Two steps with the buffer
+    // roles exchanged make one pass of the loop, so no fragment is ever moved between registers.
+    auto step = [&](int kt, bf16x8 (&cb)[8], bf16x8 (&nb)[8], bf16x8& ca7, bf16x8& na7) {
+        // This wave's share of stage kt+1 has landed (NST-2 younger stages may stay in flight) and its fragments of stage
+        // kt are in registers; after the barrier that holds for every wave, i.e. stage kt+1 is readable and stage kt's
+        // slot free.
+        static_assert((QNST - 2) * 2 * QPIECES == 16, "the s_waitcnt immediate below encodes vmcnt(16)");
+        __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0); the builtin, so that the compiler knows the fragments are in
+        __builtin_amdgcn_s_barrier();
+        const int nslot = slot + 1 == QNST ? 0 : slot + 1;
+        const char* sA = smem + nslot * QSTAGE;
+        const char* sB = sA + 16384;
+        char* wst = smem + slot * QSTAGE;
+        slot = nslot;
+        __amdgpu_buffer_rsrc_t rsa, rsb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            nb[i] = read_b(sB, i);
+            if (i > 0 && i < 8) fa[i - 1] = read_a(sA, i - 1);     // (fa[6] at i = 7; fa[7] is not used: the last A fragment lives in ca7 / na7)
+            if (i == 7) na7 = read_a(sA, 7);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mfma_inplace(acc[i][j], cb[j], i < 7 ? fa[i] : ca7);      // operands swapped: see stage_acc
+            __builtin_amdgcn_sched_barrier(0);
+            // the refill descriptors are worked out under the first row of MFMAs, not in front of it
+            if (i == 0) { rsa = dma_rsrc<A_TR>(va, (kt0 + kt + QNST) * DBK); rsb = dma_rsrc<B_TR>(vb, (kt0 + kt + QNST) * DBK); }
+            if (i < QPIECES) dma_piece(rsa, offa[i], wst + (4 * i + wave) * 1024);
+            else dma_piece(rsb, offb[i - QPIECES], wst + 16384 + (4 * (i - QPIECES) + wave) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, fb[0], fb[1], fa[7], fa7);
+        step(kt + 1, fb[1], fb[0], fa7, fa[7]);
+    }
+    if (kt < nk) step(kt, fb[0], fb[1], fa[7], fa7);
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // the fragment reads of the stage past the end are in (their registers are reused)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last MFMAs (opaque to the compiler) have written back
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // trailing refills and fragment reads are done before LDS is reused
+    __syncthreads();
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+
+    // the wave's 128x128 block goes through its private 64x64 LDS tile one quarter at a time
+    float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        f32x4 cb[4];
+        load_col_consts<EPI_STD>(p, n0 + wc * 128 + g * 64, 0, lane, cb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(cs + (i * 16 + (lane & 15)) * CS_LD + j * 16 + 4 * (lane >> 4)) = acc[4 * h + i][4 * g + j] + cb[j];
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
+            __builtin_amdgcn_wave_barrier();
+            if (p.stamps && tid == 0 && g == 0) p.stamps[(long)blockIdx.x * 8 + 3 + 2 * h] = __builtin_amdgcn_s_memtime();
+            run_epilogue_at<EPI_STD>(p, cs, m0 + wr * 128 + h * 64, n0 + wc * 128 + g * 64, 0, lane);
+            if (p.stamps && tid == 0 && g == 0 && h == 0) p.stamps[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();     // the tile is rewritten next
+        }
+    }
+    if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+}
+
 // ------------------------------------------------------------------ exact-f32 kernel (validation mode)
 template <typename T, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
@@ -1071,7 +1251,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 unsigned long long* g_stamps = nullptr;
 constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
-int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256)
+int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 quad 256x256)
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
@@ -1091,7 +1271,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         // fragment) it wins where the grid is large and K deep (the vocabulary-sized dgrad / wgrad), while
         // the small split-K weight gradients of the block measured faster on the register-staged kernel.
         // The 256-row geometry needs at least one workgroup per CU.
-        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG, KERN_WIDE };
+        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG, KERN_WIDE, KERN_QUAD };
         const bool any_km = a.a_kmajor || a.b_kmajor;
         const bool ring_ok = a.K >= DBK && ((a.K % DBK) == 0 || (a.a_kmajor && a.b_kmajor));
         const int split = a.split_k > 1 ? a.split_k : 1;
@@ -1105,10 +1285,16 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             else if (nwg >= 256 && a.K >= 2048 && split == 1) kern = KERN_RING128;
         }
         const long wide_tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        // deep-K plain products: 256x256 tiles, one workgroup per CU, as soon as every CU gets one
-        if (EPI == EPI_STD && ring_ok && a.K >= 2048 && wide_tiles * split >= WIDE_MIN_WGS) kern = KERN_WIDE;
+        // deep-K plain products: 256x256 tiles, one workgroup per CU, as soon as every CU gets one -- four waves of
+        // 128x128 (measured 4-9 % faster than eight of 128x64 from K = 1536 on), except for outputs of a handful of
+        // tiles, whose split-K slabs are mostly epilogue
+        if (EPI == EPI_STD && ring_ok && a.K >= 1536 && wide_tiles * split >= WIDE_MIN_WGS) {
+            if (wide_tiles >= 16) kern = KERN_QUAD;
+            else if (a.K >= 2048) kern = KERN_WIDE;
+        }
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && EPI == EPI_STD) kern = KERN_WIDE;
+        else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
         else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
@@ -1137,7 +1323,24 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);        \
         }                                                                                              \
     } while (0)
-        if (kern == KERN_WIDE) {
+#define CAPDEC_QUAD_LAUNCH(AT, BT)                                                                     \
+    do {                                                                                               \
+        auto kfn = gemm_bf16_quad_kernel<AT, BT>;                                                      \
+        static bool attr_set = false;                                                                  \
+        if (!attr_set) {                                                                               \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                           \
+        }                                                                                              \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)wide_tiles, split), dim3(256), QLDS, st, a);            \
+    } while (0)
+        if (kern == KERN_QUAD) {
+            if constexpr (EPI == EPI_STD) {
+                if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);
+                else if (a.a_kmajor) CAPDEC_QUAD_LAUNCH(true, false);
+                else if (a.b_kmajor) CAPDEC_QUAD_LAUNCH(false, true);
+                else CAPDEC_QUAD_LAUNCH(false, false);
+            }
+        } else if (kern == KERN_WIDE) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 4, 8, 4, wide_tiles);
                 else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 4, 8, 4, wide_tiles);
@@ -1156,6 +1359,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         else CAPDEC_GEMM_CASE(true, true);
 #undef CAPDEC_GEMM_CASE
 #undef CAPDEC_RING_LAUNCH
+#undef CAPDEC_QUAD_LAUNCH
     } else {
         static bool attr_set = false;
         if (!attr_set) {

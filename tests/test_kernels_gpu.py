@@ -61,8 +61,8 @@ def gemm_mode():
 
 
 # 1 register-staged, 2 ring 128x128, 3 ring 256x128 (8 waves), 4 ring 256x128 (4 waves of 128x64),
-# 5 ring 256x256 (8 waves of 128x64; plain products only)
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+# 5 ring 256x256 (8 waves of 128x64; plain products only), 6 256x256 with 4 waves of 128x128 (plain products only)
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 264, 192), (1000, 72, 96), (515, 640, 768), (64, 136, 64)])
 def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
     A, B = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(N, K, dtype=torch.bfloat16, scale=0.1, seed=32)
@@ -78,7 +78,7 @@ def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
     close(out2, ref + res, 1.5e-2, f"mode {mode} + residual")
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6])
 @pytest.mark.parametrize("akm,bkm", [(False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(264, 136, 96), (520, 72, 2080), (136, 264, 100)])
 def test_gemm_reduction_major_every_geometry(gemm_mode, mode, akm, bkm, M, N, K):
@@ -162,7 +162,7 @@ def test_logits_ce_backward_from_kept_numerators(dtype, tol, B_, L, V, d):
 
 
 @pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 5, 6])
 def test_gemm_split_k(gemm_mode, mode, M, N, K, out):
     gemm_mode(mode)
     # weight-gradient shape: few output tiles, deep K; both operands reduction-major

@@ -106,7 +106,21 @@ def vocabulary_cases():
     stamp_call("slab wgrad 8192x768x8192 (A,B kmajor)", lambda: ops.gemm(dl, x, dW, a_kmajor=True, b_kmajor=True), (slab // 128) * 6, slab // 64)
 
 
+def deep_k_cases():
+    """The two 256x256 kernels (forced through the diagnostic kernel switch) on main-loop-dominated products."""
+    lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
+    lib.capdecdbg_gemm_mode.restype = None
+    for mode, label in ((5, "8 waves of 128x64"), (6, "4 waves of 128x128")):
+        lib.capdecdbg_gemm_mode(mode)
+        run(f"square 8192^3, {label}", 8192, 8192, 8192)
+        run(f"wgrad-shaped 50304x768x8192 (A,B kmajor), {label}", 50304, 768, 8192, a_kmajor=True, b_kmajor=True, out=torch.float32)
+    lib.capdecdbg_gemm_mode(0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "deep":
+        deep_k_cases()
+        sys.exit(0)
     vocabulary_cases()
     bias = torch.zeros(4096, device=DEV)
     run("KV proj 58624x1536x768 (bias)", 58624, 1536, 768, bias=bias[:1536])
