@@ -1110,10 +1110,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
         fb[0][i] = read_b(smem + 16384, i);
     }
     int slot = 0;                            // ring slot of stage kt
+    // the refill of step kt reads k-tile kt0 + kt + NST: its start and the bytes addressable from there advance by a
+    // constant per step, which keeps the descriptor arithmetic inside the main loop to a few scalar instructions
+    const long stepA = (A_TR ? (long)DBK * va.ld : (long)DBK) * 2, stepB = (B_TR ? (long)DBK * vb.ld : (long)DBK) * 2;      // bytes
+    const char* refA = (const char*)va.base + (long)(kt0 + QNST) * stepA;
+    const char* refB = (const char*)vb.base + (long)(kt0 + QNST) * stepB;
+    long remA = va.remaining * 2 - (long)(kt0 + QNST) * stepA, remB = vb.remaining * 2 - (long)(kt0 + QNST) * stepB;
+    auto rsrc_at = [](const char* base, long rem) {
+        const unsigned rec = rem <= 0 ? 0u : (rem > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)rem);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)rec, 0x00020000);
+    };
     // One step: MFMAs on the fragments of stage kt (B: cb; last A: ca7, the others fa[0..6]) while those of stage kt+1 are
     // read (B: nb; last A: na7) and the slot stage kt occupied is refilled with stage kt+NST.  Two steps with the buffer
     // roles exchanged make one pass of the loop, so no fragment is ever moved between registers.
-    auto step = [&](int kt, bf16x8 (&cb)[8], bf16x8 (&nb)[8], bf16x8& ca7, bf16x8& na7) {
+    auto step = [&](bf16x8 (&cb)[8], bf16x8 (&nb)[8], bf16x8& ca7, bf16x8& na7) {
         // This wave's share of stage kt+1 has landed (NST-2 younger stages may stay in flight) and its fragments of stage
         // kt are in registers; after the barrier that holds for every wave, i.e. stage kt+1 is readable and stage kt's
         // slot free.
@@ -1128,27 +1138,34 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
         __amdgpu_buffer_rsrc_t rsa, rsb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
-            nb[i] = read_b(sB, i);
-            if (i > 0 && i < 8) fa[i - 1] = read_a(sA, i - 1);     // (fa[6] at i = 7; fa[7] is not used: the last A fragment lives in ca7 / na7)
-            if (i == 7) na7 = read_a(sA, 7);
-            __builtin_amdgcn_sched_barrier(0);
+            // the row's LDS reads and its refill piece are spread between its MFMAs (one wave per SIMD issues in order:
+            // whatever waits for a queue slot holds back the MFMAs behind it)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mfma_inplace(acc[i][j], cb[j], i < 7 ? fa[i] : ca7);      // operands swapped: see stage_acc
-            __builtin_amdgcn_sched_barrier(0);
-            // the refill descriptors are worked out under the first row of MFMAs, not in front of it
-            if (i == 0) { rsa = dma_rsrc<A_TR>(va, (kt0 + kt + QNST) * DBK); rsb = dma_rsrc<B_TR>(vb, (kt0 + kt + QNST) * DBK); }
-            if (i < QPIECES) dma_piece(rsa, offa[i], wst + (4 * i + wave) * 1024);
-            else dma_piece(rsb, offb[i - QPIECES], wst + 16384 + (4 * (i - QPIECES) + wave) * 1024);
+            for (int j = 0; j < 8; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_inplace(acc[i][j], cb[j], i < 7 ? fa[i] : ca7);      // operands swapped: see stage_acc
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) nb[i] = read_b(sB, i);
+                if (j == 3) {
+                    if (i > 0) fa[i - 1] = read_a(sA, i - 1);              // (the last A fragment lives in ca7 / na7)
+                    else { rsa = rsrc_at(refA, remA); refA += stepA; remA -= stepA; }
+                }
+                if (j == 6) {
+                    if (i < QPIECES) dma_piece(rsa, offa[i], wst + (4 * i + wave) * 1024);
+                    else dma_piece(rsb, offb[i - QPIECES], wst + 16384 + (4 * (i - QPIECES) + wave) * 1024);
+                }
+                if (j == 5 && i == 7) na7 = read_a(sA, 7);
+                if (j == 4 && i == 0) { rsb = rsrc_at(refB, remB); refB += stepB; remB -= stepB; }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        step(kt, fb[0], fb[1], fa[7], fa7);
-        step(kt + 1, fb[1], fb[0], fa7, fa[7]);
+        step(fb[0], fb[1], fa[7], fa7);
+        step(fb[1], fb[0], fa7, fa[7]);
     }
-    if (kt < nk) step(kt, fb[0], fb[1], fa[7], fa7);
+    if (kt < nk) step(fb[0], fb[1], fa[7], fa7);
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the fragment reads of the stage past the end are in (their registers are reused)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last MFMAs (opaque to the compiler) have written back
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // trailing refills and fragment reads are done before LDS is reused

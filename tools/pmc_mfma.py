@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MFMA utilisation and wave-state shares per kernel from one rocprofv3 counter pass
 (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
-SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE) over bench.py.
+SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE) over bench.py; per kernel and grid size, the median over its launches.
 
     python tools/pmc_mfma.py <counter_collection.csv> [min_us]
 
@@ -29,8 +29,10 @@ def main():
     for key, c in agg.items():
         if "GRBM_GUI_ACTIVE" not in c:
             continue
-        m = lambda k: sum(c[k]) / len(c[k]) if k in c else float("nan")        # noqa: E731
-        d = sum(dur[key]) / len(dur[key]) / 1e3
+        # medians: a kernel's first launch in a process runs several times longer than the rest
+        med = lambda v: sorted(v)[len(v) // 2]                                  # noqa: E731
+        m = lambda k: med(c[k]) if k in c else float("nan")                     # noqa: E731
+        d = med(dur[key]) / 1e3
         if d < min_us:
             continue
         gui = m("GRBM_GUI_ACTIVE") / 8
