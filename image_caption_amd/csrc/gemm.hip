@@ -1034,16 +1034,32 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(__builtin_bit_cast(u32x4, a)), "v"(__builtin_bit_cast(u32x4, b)));
 }
 
-constexpr int QNST = 4, QSTAGE = 32768, QPIECES = 4;     // 16 KiB A image + 16 KiB B image per stage; 4 + 4 DMA pieces per wave
-constexpr int QLDS = QNST * QSTAGE;
+// Geometry of the pipelined kernel: 4 waves (2 x 2), each 128 rows x 16*TJ columns.
+//   TJ = 8: 256x256 tile, 4 ring stages of 32 KiB, one workgroup per CU        (main-loop-dominated plain products)
+//   TJ = 4: 256x128 tile, 3 ring stages of 24 KiB, two workgroups per CU, whose epilogues and main loops overlap
+//           (K = 768 products with heavy epilogues); each wave keeps the MFMA pipe fed on its own, so a workgroup
+//           whose neighbour is in its epilogue does not drop to half rate
+template <int TJ> struct PipeGeo {
+    static constexpr int BN = 32 * TJ;
+    static constexpr int A_BYTES = 16384, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    static constexpr int NST = TJ == 8 ? 4 : 3;
+    static constexpr int PA = 4, PB = B_BYTES / 1024 / 4, NP = PA + PB;     // DMA pieces per wave and stage
+    static constexpr int RING = NST * STAGE;
+    static constexpr int LDS = RING > 4 * CS_WAVE_BYTES ? RING : 4 * CS_WAVE_BYTES;
+    static constexpr int WG_PER_CU = TJ == 8 ? 1 : 2;
+};
+// s_waitcnt immediate (gfx9 layout: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8]); expcnt is left alone
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8); }
 
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
+template <bool A_TR, bool B_TR, int EPI, int TJ>
+__global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    using G = PipeGeo<TJ>;
+    constexpr int NST = G::NST, STAGE = G::STAGE, PA = G::PA, PB = G::PB, NP = G::NP, WCOLS = 16 * TJ;
+    const int tm = (p.M + 255) / 256, tn = (p.N + G::BN - 1) / G::BN;
     int tile_m, tile_n;
     map_tile(tm, tn, tile_m, tile_n);
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int m0 = tile_m * 256, n0 = tile_n * G::BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -1055,17 +1071,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
     if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
     else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
     vb.ld = p.ldb; vb.rows_left = p.N - n0;
-    unsigned offa[QPIECES], offb[QPIECES];
+    unsigned offa[PA], offb[PB];
 #pragma unroll
-    for (int j = 0; j < QPIECES; ++j) {
-        offa[j] = dma_src_offset<A_TR>(va, 4 * j + wave, lane);
-        offb[j] = dma_src_offset<B_TR>(vb, 4 * j + wave, lane);
-    }
-    f32x4 acc[8][8];
+    for (int j = 0; j < PA; ++j) offa[j] = dma_src_offset<A_TR>(va, 4 * j + wave, lane);
+#pragma unroll
+    for (int j = 0; j < PB; ++j) offb[j] = dma_src_offset<B_TR>(vb, 4 * j + wave, lane);
+    // column constants of the epilogue: with two workgroups per CU fetched now and used after the main loop; the
+    // 256-wide tile has no registers to park them in and fetches them after it
+    f32x4 cb[4];
+    if constexpr (TJ == 4) load_col_consts<EPI>(p, n0 + wc * WCOLS, 0, lane, cb);
+    f32x4 acc[8][TJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_total = (p.K + DBK - 1) / DBK;
     int kt0 = 0, nk = nk_total;
@@ -1079,83 +1098,85 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
     // all NST stages go out at once; a stage index past the last k-tile still issues its (harmless) loads, so that the
     // number of DMA instructions in flight -- what vmcnt counts -- is the same in every iteration
 #pragma unroll
-    for (int s = 0; s < QNST; ++s) {
-        dma_tile<A_TR, QPIECES, 4>(va, offa, (kt0 + s) * DBK, smem + s * QSTAGE, wave);
-        dma_tile<B_TR, QPIECES, 4>(vb, offb, (kt0 + s) * DBK, smem + s * QSTAGE + 16384, wave);
+    for (int s = 0; s < NST; ++s) {
+        dma_tile<A_TR, PA, 4>(va, offa, (kt0 + s) * DBK, smem + s * STAGE, wave);
+        dma_tile<B_TR, PB, 4>(vb, offb, (kt0 + s) * DBK, smem + s * STAGE + G::A_BYTES, wave);
     }
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
 
-    // B fragments are double-buffered (every MFMA row of a step uses all eight); an A fragment is dead once its row of
+    // B fragments are double-buffered (every MFMA row of a step uses all of them); an A fragment is dead once its row of
     // MFMAs has been issued, so the next step's takes its place while the following row runs (the last one goes
     // through a spare register), which puts every LDS read at least one MFMA row before the end of the step.
-    bf16x8 fa[8], fb[2][8], fa7;
-    int troff[(A_TR || B_TR) ? 8 : 1];       // lane offsets of the eight 16-row fragments inside a reduction-major sub-image
-    if constexpr (A_TR || B_TR) {
+    bf16x8 fa[8], fb[2][TJ], fa7;
+    int troffA[A_TR ? 8 : 1], troffB[B_TR ? TJ : 1];     // lane offsets of the 16-row fragments inside a reduction-major sub-image
+    if constexpr (A_TR) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) troff[i] = tr_lane_offset(i * 16, lane);
+        for (int i = 0; i < 8; ++i) troffA[i] = tr_lane_offset(i * 16, lane);
+    }
+    if constexpr (B_TR) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) troffB[j] = tr_lane_offset(((wc * WCOLS) & 127) + j * 16, lane);
     }
     auto read_a = [&](const char* sA, int i) {
-        if constexpr (A_TR) return read_frag_tr_opaque(lds_addr(sA + wr * DTILE_BYTES) + troff[i]);
+        if constexpr (A_TR) return read_frag_tr_opaque(lds_addr(sA + wr * DTILE_BYTES) + troffA[i]);
         else return dread_frag<false>(sA, wr * 128 + i * 16, lane);
     };
-    auto read_b = [&](const char* sB, int i) {
-        if constexpr (B_TR) return read_frag_tr_opaque(lds_addr(sB + wc * DTILE_BYTES) + troff[i]);
-        else return dread_frag<false>(sB, wc * 128 + i * 16, lane);
+    auto read_b = [&](const char* sB, int j) {
+        if constexpr (B_TR) return read_frag_tr_opaque(lds_addr(sB + ((wc * WCOLS) >> 7) * DTILE_BYTES) + troffB[j]);
+        else return dread_frag<false>(sB, wc * WCOLS + j * 16, lane);
     };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QNST - 1) * 2 * QPIECES) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * NP) : "memory");
     __builtin_amdgcn_s_barrier();            // stage 0 has landed
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        fa[i] = read_a(smem, i);
-        fb[0][i] = read_b(smem + 16384, i);
-    }
+    for (int i = 0; i < 8; ++i) fa[i] = read_a(smem, i);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) fb[0][j] = read_b(smem + G::A_BYTES, j);
     int slot = 0;                            // ring slot of stage kt
     // the refill of step kt reads k-tile kt0 + kt + NST: its start and the bytes addressable from there advance by a
     // constant per step, which keeps the descriptor arithmetic inside the main loop to a few scalar instructions
     const long stepA = (A_TR ? (long)DBK * va.ld : (long)DBK) * 2, stepB = (B_TR ? (long)DBK * vb.ld : (long)DBK) * 2;      // bytes
-    const char* refA = (const char*)va.base + (long)(kt0 + QNST) * stepA;
-    const char* refB = (const char*)vb.base + (long)(kt0 + QNST) * stepB;
-    long remA = va.remaining * 2 - (long)(kt0 + QNST) * stepA, remB = vb.remaining * 2 - (long)(kt0 + QNST) * stepB;
+    const char* refA = (const char*)va.base + (long)(kt0 + NST) * stepA;
+    const char* refB = (const char*)vb.base + (long)(kt0 + NST) * stepB;
+    long remA = va.remaining * 2 - (long)(kt0 + NST) * stepA, remB = vb.remaining * 2 - (long)(kt0 + NST) * stepB;
     auto rsrc_at = [](const char* base, long rem) {
         const unsigned rec = rem <= 0 ? 0u : (rem > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)rem);
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)rec, 0x00020000);
     };
-    // One step: MFMAs on the fragments of stage kt (B: cb; last A: ca7, the others fa[0..6]) while those of stage kt+1 are
-    // read (B: nb; last A: na7) and the slot stage kt occupied is refilled with stage kt+NST.  Two steps with the buffer
-    // roles exchanged make one pass of the loop, so no fragment is ever moved between registers.
-    auto step = [&](bf16x8 (&cb)[8], bf16x8 (&nb)[8], bf16x8& ca7, bf16x8& na7) {
+    // One step: MFMAs on the fragments of stage kt (B: cbf; last A: ca7, the others fa[0..6]) while those of stage kt+1
+    // are read (B: nb; last A: na7) and the slot stage kt occupied is refilled with stage kt+NST.  Two steps with the
+    // buffer roles exchanged make one pass of the loop, so no fragment is ever moved between registers.
+    auto step = [&](bf16x8 (&cbf)[TJ], bf16x8 (&nb)[TJ], bf16x8& ca7, bf16x8& na7) {
         // This wave's share of stage kt+1 has landed (NST-2 younger stages may stay in flight) and its fragments of stage
         // kt are in registers; after the barrier that holds for every wave, i.e. stage kt+1 is readable and stage kt's
-        // slot free.
-        static_assert((QNST - 2) * 2 * QPIECES == 16, "the s_waitcnt immediate below encodes vmcnt(16)");
-        __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0); the builtin, so that the compiler knows the fragments are in
+        // slot free.  (The builtin, so that the compiler knows the fragments are in.)
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm((NST - 2) * NP, 0));
         __builtin_amdgcn_s_barrier();
-        const int nslot = slot + 1 == QNST ? 0 : slot + 1;
-        const char* sA = smem + nslot * QSTAGE;
-        const char* sB = sA + 16384;
-        char* wst = smem + slot * QSTAGE;
+        const int nslot = slot + 1 == NST ? 0 : slot + 1;
+        const char* sA = smem + nslot * STAGE;
+        const char* sB = sA + G::A_BYTES;
+        char* wst = smem + slot * STAGE;
         slot = nslot;
         __amdgpu_buffer_rsrc_t rsa, rsb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // the row's LDS reads and its refill piece are spread between its MFMAs (one wave per SIMD issues in order:
-            // whatever waits for a queue slot holds back the MFMAs behind it)
+            // the row's LDS reads and its refill piece are spread between its MFMAs (a wave issues in order: whatever
+            // waits for a queue slot holds back the MFMAs behind it)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_inplace(acc[i][j], cb[j], i < 7 ? fa[i] : ca7);      // operands swapped: see stage_acc
+                mfma_inplace(acc[i][j], cbf[j], i < 7 ? fa[i] : ca7);     // operands swapped: see stage_acc
                 __builtin_amdgcn_sched_barrier(0);
-                if (j == 0) nb[i] = read_b(sB, i);
-                if (j == 3) {
+                if (j == 0 && i < TJ) nb[i] = read_b(sB, i);
+                if (j == TJ / 2 - 1) {
                     if (i > 0) fa[i - 1] = read_a(sA, i - 1);              // (the last A fragment lives in ca7 / na7)
                     else { rsa = rsrc_at(refA, remA); refA += stepA; remA -= stepA; }
                 }
-                if (j == 6) {
-                    if (i < QPIECES) dma_piece(rsa, offa[i], wst + (4 * i + wave) * 1024);
-                    else dma_piece(rsb, offb[i - QPIECES], wst + 16384 + (4 * (i - QPIECES) + wave) * 1024);
+                if (j == TJ / 2 && i == 0) { rsb = rsrc_at(refB, remB); refB += stepB; remB -= stepB; }
+                if (j == TJ - 3 && i == 7) na7 = read_a(sA, 7);
+                if (j == TJ - 2 && i < NP) {
+                    if (i < PA) dma_piece(rsa, offa[i], wst + (4 * i + wave) * 1024);
+                    else dma_piece(rsb, offb[i - PA], wst + G::A_BYTES + (4 * (i - PA) + wave) * 1024);
                 }
-                if (j == 5 && i == 7) na7 = read_a(sA, 7);
-                if (j == 4 && i == 0) { rsb = rsrc_at(refB, remB); refB += stepB; remB -= stepB; }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1172,12 +1193,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
     __syncthreads();
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
 
-    // the wave's 128x128 block goes through its private 64x64 LDS tile one quarter at a time
+    // the wave's block goes through its private 64x64 LDS tile one 64x64 piece at a time
     float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        f32x4 cb[4];
-        load_col_consts<EPI_STD>(p, n0 + wc * 128 + g * 64, 0, lane, cb);
+    for (int g = 0; g < TJ / 4; ++g) {
+        const int nw = n0 + wc * WCOLS + g * 64;
+        if constexpr (TJ != 4) load_col_consts<EPI>(p, nw, 0, lane, cb);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1188,10 +1209,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_quad_kernel(GemmArgs p) {
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own wave's LDS writes landed
             __builtin_amdgcn_wave_barrier();
             if (p.stamps && tid == 0 && g == 0) p.stamps[(long)blockIdx.x * 8 + 3 + 2 * h] = __builtin_amdgcn_s_memtime();
-            run_epilogue_at<EPI_STD>(p, cs, m0 + wr * 128 + h * 64, n0 + wc * 128 + g * 64, 0, lane);
+            run_epilogue_at<EPI>(p, cs, m0 + wr * 128 + h * 64, nw, nw >> 6, lane);
             if (p.stamps && tid == 0 && g == 0 && h == 0) p.stamps[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();     // the tile is rewritten next
         }
     }
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -1268,7 +1287,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 unsigned long long* g_stamps = nullptr;
 constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
-int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 quad 256x256)
+int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 pipelined 256x256, 7 pipelined 256x128)
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
@@ -1288,7 +1307,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         // fragment) it wins where the grid is large and K deep (the vocabulary-sized dgrad / wgrad), while
         // the small split-K weight gradients of the block measured faster on the register-staged kernel.
         // The 256-row geometry needs at least one workgroup per CU.
-        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG, KERN_WIDE, KERN_QUAD };
+        enum { KERN_REG, KERN_RING128, KERN_TALL, KERN_BIG, KERN_WIDE, KERN_QUAD, KERN_TALLP };
         const bool any_km = a.a_kmajor || a.b_kmajor;
         const bool ring_ok = a.K >= DBK && ((a.K % DBK) == 0 || (a.a_kmajor && a.b_kmajor));
         const int split = a.split_k > 1 ? a.split_k : 1;
@@ -1312,6 +1331,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && EPI == EPI_STD) kern = KERN_WIDE;
         else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
+        else if (g_gemm_mode == 7 && ring_ok && !any_km) kern = KERN_TALLP;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
         else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
@@ -1340,16 +1360,19 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);        \
         }                                                                                              \
     } while (0)
-#define CAPDEC_QUAD_LAUNCH(AT, BT)                                                                     \
+#define CAPDEC_PIPE_LAUNCH(AT, BT, E, TJ, NWG)                                                         \
     do {                                                                                               \
-        auto kfn = gemm_bf16_quad_kernel<AT, BT>;                                                      \
+        auto kfn = gemm_bf16_pipe_kernel<AT, BT, E, TJ>;                                               \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)wide_tiles, split), dim3(256), QLDS, st, a);            \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(256), PipeGeo<TJ>::LDS, st, a);     \
     } while (0)
+#define CAPDEC_QUAD_LAUNCH(AT, BT) CAPDEC_PIPE_LAUNCH(AT, BT, EPI_STD, 8, wide_tiles)
+        if (kern == KERN_TALLP) CAPDEC_PIPE_LAUNCH(false, false, EPI, 4, big_tiles);
+        else
         if (kern == KERN_QUAD) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);
@@ -1377,6 +1400,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 #undef CAPDEC_GEMM_CASE
 #undef CAPDEC_RING_LAUNCH
 #undef CAPDEC_QUAD_LAUNCH
+#undef CAPDEC_PIPE_LAUNCH
     } else {
         static bool attr_set = false;
         if (!attr_set) {

@@ -61,8 +61,9 @@ def gemm_mode():
 
 
 # 1 register-staged, 2 ring 128x128, 3 ring 256x128 (8 waves), 4 ring 256x128 (4 waves of 128x64),
-# 5 ring 256x256 (8 waves of 128x64; plain products only), 6 256x256 with 4 waves of 128x128 (plain products only)
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
+# 5 ring 256x256 (8 waves of 128x64; plain products only), 6 pipelined 256x256 with 4 waves of 128x128 (plain products
+# only), 7 pipelined 256x128 with 4 waves of 128x64 (row-major operands)
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 264, 192), (1000, 72, 96), (515, 640, 768), (64, 136, 64)])
 def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
     A, B = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(N, K, dtype=torch.bfloat16, scale=0.1, seed=32)
@@ -96,7 +97,7 @@ def test_gemm_reduction_major_every_geometry(gemm_mode, mode, akm, bkm, M, N, K)
     close(out, ref, 1.5e-2, f"mode {mode}")
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 7])
 def test_logits_ce_every_geometry(gemm_mode, mode):
     B_, L, V, d = 5, 8, 1111, 64                       # 40 rows: ragged in M; 1111 columns: ragged in N
     M = B_ * L

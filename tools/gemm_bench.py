@@ -103,7 +103,7 @@ def main():
     t_with = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, dbias, bws), 20)
     t_without = timeit(lambda: ops.logits_ce_bwd_slab(x_t, wv, bias_v, labels, B, L, lse, 1.0 / Mt, 0, slab, dl, None), 20)
     print(f"CE bwd slab: with bias gradient {t_with * 1e3:.1f} us, without {t_without * 1e3:.1f} us")
-    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU) | ring 256x256 | quad 256x256 (both plain products only)")
+    print("A/B (TFLOP/s, median of 5 interleaved rounds): register | ring128 | ring256 (8 waves) | ring256 (4 waves, 2 WG/CU) | ring 256x256 | pipelined 256x256 (both plain products only) | pipelined 256x128")
     Vp = (V + 127) // 128 * 128
     dlw = torch.zeros(Mt, Vp, device=DEV, dtype=BF)
     dlw[:, :V] = (torch.randn(Mt, V, device=DEV, generator=g) * 1e-3).to(BF)
@@ -137,14 +137,14 @@ def main():
         lib.capdecdbg_gemm_mode(0)
         print(f"{name:48s} " + " | ".join(f"{sorted(res[m])[2]:7.1f}" for m in (1, 2, 4, 5, 6, 0)))
     for name, (fl, fn) in cases.items():
-        res = {1: [], 2: [], 3: [], 4: [], 5: [], 6: []}
+        res = {1: [], 2: [], 3: [], 4: [], 5: [], 6: [], 7: []}
         for _ in range(5):
-            for mode in (1, 2, 3, 4, 5, 6):
+            for mode in (1, 2, 3, 4, 5, 6, 7):
                 lib.capdecdbg_gemm_mode(mode)
                 res[mode].append(fl / timeit(fn, 5) / 1e9)
         lib.capdecdbg_gemm_mode(0)
         med = {m: sorted(v)[2] for m, v in res.items()}
-        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f} | {med[4]:7.1f} | {med[5]:7.1f} | {med[6]:7.1f}")
+        print(f"{name:34s} {med[1]:7.1f} | {med[2]:7.1f} | {med[3]:7.1f} | {med[4]:7.1f} | {med[5]:7.1f} | {med[6]:7.1f} | {med[7]:7.1f}")
 
 
 if __name__ == "__main__":
