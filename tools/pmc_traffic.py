@@ -18,8 +18,8 @@ import sys
 LAUNCHES = {
     "logits_ce_fwd": ("gemm_bf16_dma_kernel<false, false, 1, 2, 2, 8, 3>", None),
     "logits_ce_bwd_slab": ("gemm_bf16_dma_kernel<false, false, 2, 2, 2, 8, 3>", None),
-    "head_wgrad_slab": ("gemm_bf16_quad_kernel<true, true>", 197 * 3 * 256),
-    "head_dgrad_slab": ("gemm_bf16_quad_kernel<false, true>", 32 * 3 * 8 * 256),
+    "head_wgrad_slab": ("gemm_bf16_pipe_kernel<true, true, 0, 8>", 197 * 3 * 256),
+    "head_dgrad_slab": ("gemm_bf16_pipe_kernel<false, true, 0, 8>", 32 * 3 * 8 * 256),
 }
 
 
