@@ -112,6 +112,10 @@ SIGNATURES = {
     "capdec_seqfirst_ln_bwd_affine": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "capdec_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "capdec_ln_fold_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "capdec_ln_fold_bwd_workspace": (c_long, [c_int, c_int]),
+    "capdec_ln_fold_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "capdec_ln_bwd_workspace": (c_long, [c_long, c_int]),
     "capdec_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -380,6 +380,55 @@ __global__ void greedy_update_kernel(int64_t* ids, uint8_t* done, int64_t* out, 
     if (tok == eos) done[b] = 1;
 }
 
+// ------------------------------------------------------------------ LayerNorm affine folded into the Linear that follows it
+// y = (xhat*gamma + beta) W^T + b = xhat (W*gamma)^T + (b + W beta): the Linear can consume the normalised rows
+// directly.  One wave per output row j: Wf[j,:] = W[j,:] * gamma, bf[j] = b[j] + sum_c W[j,c] beta[c].
+template <typename TW, typename TO>
+__global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const TW* W, long ldw, const float* bias, const float* gamma, const float* beta,
+                                                          int N, int K, TO* Wf, long ldwf, float* bf) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= N) return;
+    float acc = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        const f32x4 w = load4<TW>(W + (long)j * ldw + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = w[e] * g[e]; acc += w[e] * b[e]; }
+        store4<TO>(Wf + (long)j * ldwf + c, o);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) bf[j] = (bias ? bias[j] : 0.f) + acc;
+}
+
+// The backward of that folding.  G = dY^T xhat (the weight-gradient product taken with the normalised rows) and
+// s = column sums of dY (the bias gradient) give everything the LayerNorm + Linear pair owes:
+//   dW[j,c] = gamma[c] G[j,c] + beta[c] s[j]        (in place over G)
+//   dgamma[c] = sum_j W[j,c] G[j,c],   dbeta[c] = sum_j W[j,c] s[j]
+// -- no product back to the rows (dY W) and no pass over the rows.  A block owns 32 rows j and writes one partial
+// row pair [2][K]; ln_bwd_finalize_kernel folds the blocks in a fixed order.
+template <typename TW>
+__global__ __launch_bounds__(256) void ln_fold_bwd_kernel(float* G, long ldg, const float* s, const TW* W, long ldw, const float* gamma,
+                                                          const float* beta, int N, int K, float* partial) {
+    const int j0 = blockIdx.x * 32, j1 = min(N, j0 + 32);
+    for (int c = threadIdx.x * 4; c < K; c += 1024) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+        for (int j = j0; j < j1; ++j) {
+            const f32x4 w = load4<TW>(W + (long)j * ldw + c);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(G + (long)j * ldg + c);
+            const float sj = s[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dg[e] += w[e] * gv[e]; db[e] += w[e] * sj; gv[e] = g[e] * gv[e] + b[e] * sj; }
+            *reinterpret_cast<f32x4*>(G + (long)j * ldg + c) = gv;
+        }
+        *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * 2) * K + c) = dg;
+        *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * 2 + 1) * K + c) = db;
+    }
+}
+
 int grid_for(long n, int per_block, int cap = 4096) {
     long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -636,6 +685,44 @@ extern "C" int capdec_greedy_update(int64_t* ids, uint8_t* done, int64_t* out, i
                                     int64_t eos_id, int64_t pad_id, void* stream) {
     CAPDEC_CHECK(ids && done && out && B > 0 && t >= 0 && t < L, "greedy_update: bad arguments");
     hipLaunchKernelGGL(greedy_update_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, done, out, B, L, t, eos_id, pad_id);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_ln_fold_fwd(const void* W, int w_dtype, long ldw, const float* bias, const float* gamma, const float* beta,
+                                  int N, int K, void* Wf, int wf_dtype, long ldwf, float* bf, void* stream) {
+    CAPDEC_CHECK(W && gamma && beta && Wf && bf, "ln_fold_fwd: null pointer");
+    const int al = w_dtype == CAPDEC_BF16 ? 8 : 4, alf = wf_dtype == CAPDEC_BF16 ? 8 : 4;
+    CAPDEC_CHECK(N > 0 && K > 0 && (K % 4) == 0 && (ldw % al) == 0 && (ldwf % alf) == 0 && aligned16(W) && aligned16(Wf) && aligned16(gamma) && aligned16(beta),
+                 "ln_fold_fwd: K must be a multiple of 4, rows 16-byte aligned (K=%d, ldw=%ld, ldwf=%ld)", K, ldw, ldwf);
+    CAPDEC_CHECK(w_dtype == CAPDEC_F32 || wf_dtype == CAPDEC_BF16, "ln_fold_fwd: a bf16 matrix folds into a bf16 matrix");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + 3) / 4), block(256);
+    if (w_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL((ln_fold_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)W, ldw, bias, gamma, beta, N, K, (bf16_t*)Wf, ldwf, bf);
+    else if (wf_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL((ln_fold_fwd_kernel<float, bf16_t>), grid, block, 0, st, (const float*)W, ldw, bias, gamma, beta, N, K, (bf16_t*)Wf, ldwf, bf);
+    else
+        hipLaunchKernelGGL((ln_fold_fwd_kernel<float, float>), grid, block, 0, st, (const float*)W, ldw, bias, gamma, beta, N, K, (float*)Wf, ldwf, bf);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" long capdec_ln_fold_bwd_workspace(int N, int K) { return (long)((N + 31) / 32) * 2 * K * 4; }
+
+extern "C" int capdec_ln_fold_bwd(float* G, long ldg, const float* s, const void* W, int w_dtype, long ldw, const float* gamma, const float* beta,
+                                  int N, int K, float* dgamma, float* dbeta, void* partial, void* stream) {
+    CAPDEC_CHECK(G && s && W && gamma && beta && dgamma && dbeta && partial, "ln_fold_bwd: null pointer");
+    const int al = w_dtype == CAPDEC_BF16 ? 8 : 4;
+    CAPDEC_CHECK(N > 0 && K > 0 && (K % 4) == 0 && (ldg % 4) == 0 && (ldw % al) == 0 && aligned16(G) && aligned16(W) && aligned16(gamma) && aligned16(beta) && aligned16(partial),
+                 "ln_fold_bwd: K must be a multiple of 4, rows 16-byte aligned (K=%d, ldg=%ld, ldw=%ld)", K, ldg, ldw);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (N + 31) / 32;
+    if (w_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL(ln_fold_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, G, ldg, s, (const bf16_t*)W, ldw, gamma, beta, N, K, (float*)partial);
+    else
+        hipLaunchKernelGGL(ln_fold_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, G, ldg, s, (const float*)W, ldw, gamma, beta, N, K, (float*)partial);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, K, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import config
-from .engine import (BLOCK_PARAM_SHAPES, HEAD_B, HEAD_W, MATRIX_KEYS, DecoderEngine, EngineOptions, ModelGeometry,
+from .engine import (BLOCK_PARAM_SHAPES, HEAD_B, HEAD_W, IN_PROJ_MASTER, MATRIX_KEYS, DecoderEngine, EngineOptions, ModelGeometry,
                      ParamStore, _Weights, block_key, weights_from_store)
 
 
@@ -111,6 +111,8 @@ class TransformerDecoder(nn.Module):
             for name, _ in BLOCK_PARAM_SHAPES:
                 key = block_key(i, name, self.n_blocks)
                 b[name] = mat(key) if name in MATRIX_KEYS else named[key].detach()
+            if i == 0:
+                b[IN_PROJ_MASTER] = named[block_key(0, "self_attn.in_proj_weight", self.n_blocks)].detach()
             blocks.append(b)
         return _Weights(blocks, mat(HEAD_W), named[HEAD_B].detach())
 

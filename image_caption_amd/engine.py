@@ -57,6 +57,7 @@ class EngineOptions:
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
     composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
+    fold_norm1: bool = True                       # training without input gradient: block 0's norm1 affine is folded into in_proj
     dropout_seed: int = 42
 
 
@@ -158,6 +159,9 @@ class KernelTimer:
         return out
 
 
+IN_PROJ_MASTER = "self_attn.in_proj_weight.f32"       # block 0 only: the f32 parameter behind the compute-dtype matrix
+
+
 class _Weights:
     """Per-call view of the tensors the kernels read: matrices in compute dtype,
     biases / LayerNorm affine in f32."""
@@ -177,6 +181,8 @@ def weights_from_store(store: ParamStore) -> _Weights:
         for name, _ in BLOCK_PARAM_SHAPES:
             key = block_key(i, name, geo.n_blocks)
             b[name] = store.compute(key) if name in MATRIX_KEYS else store.param(key)
+        if i == 0:
+            b[IN_PROJ_MASTER] = store.param(block_key(0, "self_attn.in_proj_weight", geo.n_blocks))
         blocks.append(b)
     return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows)
 
@@ -215,6 +221,14 @@ class DecoderEngine:
             t.zero_()
         return t
 
+    def _unit_affine(self, d, dev):
+        key = ("unit_affine", d, str(dev))
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.ones(d, dtype=torch.float32, device=dev), torch.zeros(d, dtype=torch.float32, device=dev))
+            self._bufs[key] = t
+        return t
+
     def _on_side_stream(self, fn):
         """Runs fn (launches of kernels nothing downstream in this backward waits for: the block's
         weight-gradient products) on a second stream, ordered after everything issued so far on the
@@ -243,7 +257,7 @@ class DecoderEngine:
         return ops.dropout_keys(self.opt.dropout_seed, site, step, p)
 
     # ------------------------------------------------------------------ one block, forward
-    def _block_fwd(self, i, W, x_in, B, S, q_start, train, step, dev, h1_ready=None):
+    def _block_fwd(self, i, W, x_in, B, S, q_start, train, step, dev, h1_ready=None, in_proj=None):
         """x_in [S*B,d] f32 -> rows q_start*B.. of the block output [Mt,d] f32.  Saves
         what the backward needs in self.saved[i]."""
         geo, cdt = self.geo, self.cdt
@@ -261,7 +275,8 @@ class DecoderEngine:
             h1, mean1, rstd1 = h1_ready
         qkv = self.buf(f"qkv.{i}", (M, 3 * d), cdt, dev)
         scale = hd ** -0.5
-        in_w, in_b = w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"]
+        # in_proj: the block's own, or the pair with norm1's affine folded in (h1 then holds the normalised rows)
+        in_w, in_b = in_proj if in_proj is not None else (w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"])
         if q_start == 0:
             ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d)
         else:
@@ -289,13 +304,14 @@ class DecoderEngine:
         k_r2 = self._keys(4 * i + 3, step, train)
         ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid)
         sv.update(x_in=x_in, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x_mid=x_mid, h2=h2,
-                  mean2=mean2, rstd2=rstd2, a1=a1, z1=z1, q_start=q_start, keys=(k_attn, k_r1, k_h, k_r2))
+                  mean2=mean2, rstd2=rstd2, a1=a1, z1=z1, q_start=q_start, keys=(k_attn, k_r1, k_h, k_r2),
+                  folded=in_proj is not None)
         self.saved[i] = sv
         return x_out
 
     # ------------------------------------------------------------------ forward to the scored rows
     def forward_hidden(self, W: _Weights, source, *, L_scored: Optional[int], train: bool, step: int = 0, pos=None,
-                       keep_joined: bool = True):
+                       keep_joined: bool = True, fold_norm1: bool = False):
         """source = ("concat", img, sos, cap) or ("tensor", tgt[S,B,d]).  Returns
         (x [rows, d] f32 of the last block, first row index r0, B, S)."""
         geo = self.geo
@@ -323,6 +339,19 @@ class DecoderEngine:
             q0 = last_q0 if i == nb - 1 else 0
             if i == 0:
                 w0 = W.blocks[0]
+                g1, b1 = w0["norm1.weight"], w0["norm1.bias"]
+                in_proj = None
+                if fold_norm1:
+                    # self_attn(norm1(x)) = xhat (W*gamma)^T + (b + W beta): the LayerNorm kernels write the normalised
+                    # rows (unit weight, zero bias) and the projection takes the folded pair.  What that buys is in the
+                    # backward: no product back to the rows and no pass over them for norm1's affine gradients.
+                    # (from the f32 parameter where the caller supplies it: one rounding to the compute dtype, not two)
+                    in_w0 = w0.get(IN_PROJ_MASTER, w0["self_attn.in_proj_weight"])
+                    wf = self.buf("in_proj_w_folded", tuple(in_w0.shape), self.cdt, dev)
+                    bf = self.buf("in_proj_b_folded", (in_w0.shape[0],), torch.float32, dev)
+                    ops.ln_fold_fwd(in_w0, w0["self_attn.in_proj_bias"], g1, b1, wf, bf)
+                    in_proj = (wf, bf)
+                    g1, b1 = self._unit_affine(d, dev)
                 h1 = self.buf("h1.0", (M, d), self.cdt, dev)
                 mean1 = self.buf("mean1.0", (M,), torch.float32, dev)
                 rstd1 = self.buf("rstd1.0", (M,), torch.float32, dev)
@@ -332,7 +361,7 @@ class DecoderEngine:
                     # LayerNorm backward that must return an input gradient): otherwise they are not kept, and
                     # the backward reads img / sos / cap again
                     x0 = self.buf("x0", (M, d), torch.float32, dev)
-                    ops.concat_ln_fwd(img, sos, cap, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0,
+                    ops.concat_ln_fwd(img, sos, cap, g1, b1, pos=pos, x_out=x0,
                                       x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
                     concat_src = ("concat", img, sos, cap, pos)
                 elif (tgt.dtype in (torch.float32, torch.bfloat16) and tgt.stride(2) == 1 and tgt.data_ptr() % 16 == 0
@@ -340,15 +369,15 @@ class DecoderEngine:
                       and (pos is not None or not keep_joined or tgt.dtype != torch.float32 or not tgt.is_contiguous())):
                     # a strided seq-first slice (dataset[:, i:j, :]) is normalised where it lies: no contiguous copy
                     x0 = self.buf("x0", (M, d), torch.float32, dev)
-                    ops.seqfirst_ln_fwd(tgt, w0["norm1.weight"], w0["norm1.bias"], pos=pos, x_out=x0,
+                    ops.seqfirst_ln_fwd(tgt, g1, b1, pos=pos, x_out=x0,
                                         x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
                     concat_src = ("seqfirst", tgt, pos)
                 else:
                     x0 = tgt.reshape(M, d)
                     if x0.dtype != torch.float32 or not x0.is_contiguous():
                         x0 = x0.float().contiguous()
-                    ops.ln_fwd(x0, w0["norm1.weight"], w0["norm1.bias"], h1, mean1, rstd1)
-                x = self._block_fwd(0, W, x0, B, S, q0, train, step, dev, h1_ready=(h1, mean1, rstd1))
+                    ops.ln_fwd(x0, g1, b1, h1, mean1, rstd1)
+                x = self._block_fwd(0, W, x0, B, S, q0, train, step, dev, h1_ready=(h1, mean1, rstd1), in_proj=in_proj)
                 self.saved[0]["concat_src"] = concat_src
             else:
                 x = self._block_fwd(i, W, x, B, S, q0, train, step, dev)
@@ -367,7 +396,8 @@ class DecoderEngine:
         _lib.require_cuda(labels)
         Bl, L = labels.shape
         x, r0, B, S = self.forward_hidden(W, source, L_scored=L, train=train, step=step, pos=pos,
-                                          keep_joined=need_input_grad or not want_grads)
+                                          keep_joined=need_input_grad or not want_grads,
+                                          fold_norm1=want_grads and not need_input_grad and self.opt.fold_norm1)
         assert Bl == B, "labels batch does not match inputs"
         dev = labels.device
         Mh = L * B
@@ -502,6 +532,14 @@ class DecoderEngine:
             self._on_side_stream(in_proj_wgrads)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
+        if sv.get("folded"):
+            # norm1's affine was folded into in_proj: gin_w holds G = dQKV^T xhat and gin_b the column sums of dQKV,
+            # from which the weight gradient proper and norm1's affine gradients follow without touching the rows again
+            assert not need_dx_in
+            self._join_side_stream()
+            fws = self.buf("ln_fold_ws", (ops.ln_fold_bwd_workspace(3 * d, d),), torch.uint8, dev)
+            ops.ln_fold_bwd(gin_w, gin_b, in_w, w["norm1.weight"], w["norm1.bias"], G("norm1.weight"), G("norm1.bias"), fws)
+            return None
         if not need_dx_in:
             # no gradient flows below this block: dh1 only feeds norm1's affine gradients, so it is kept in
             # the compute dtype, rows below / from r0 come from two products over disjoint rows, and the

@@ -90,6 +90,29 @@ def ln_fwd(x, gamma, beta, y_out, mean=None, rstd=None, eps=1e-5):
           "capdec_ln_fwd")
 
 
+def ln_fold_fwd(W, bias, gamma, beta, Wf, bf):
+    """Wf = W * gamma (per input column), bf = bias + W @ beta: LayerNorm's affine folded into the Linear after it."""
+    require_cuda(W, bias, gamma, beta, Wf, bf)
+    N, K = W.shape
+    assert Wf.shape == W.shape and bf.shape == (N,) and bf.dtype == torch.float32
+    check(_lib.load().capdec_ln_fold_fwd(ptr(W), dtype_code(W), _ld(W), ptr(bias), ptr(gamma), ptr(beta), N, K, ptr(Wf), dtype_code(Wf),
+                                         _ld(Wf), ptr(bf), _st()), "capdec_ln_fold_fwd")
+
+
+def ln_fold_bwd_workspace(N, K) -> int:
+    return _lib.load().capdec_ln_fold_bwd_workspace(N, K)
+
+
+def ln_fold_bwd(G, s, W, gamma, beta, dgamma, dbeta, partial):
+    """G [N,K] f32 = dY^T xhat becomes the Linear's weight gradient in place; dgamma / dbeta are overwritten."""
+    require_cuda(G, s, W, gamma, beta, dgamma, dbeta, partial)
+    N, K = W.shape
+    assert G.shape == (N, K) and G.dtype == torch.float32 and s.shape == (N,) and s.dtype == torch.float32
+    assert partial.numel() * partial.element_size() >= ln_fold_bwd_workspace(N, K)
+    check(_lib.load().capdec_ln_fold_bwd(ptr(G), _ld(G), ptr(s), ptr(W), dtype_code(W), _ld(W), ptr(gamma), ptr(beta), N, K,
+                                         ptr(dgamma), ptr(dbeta), ptr(partial), _st()), "capdec_ln_fold_bwd")
+
+
 def ln_bwd_workspace(M, d) -> int:
     return _lib.load().capdec_ln_bwd_workspace(M, d)
 

@@ -90,6 +90,20 @@ int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
                   const float* mean, const float* rstd, long M, int d,
                   const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
                   void* partial, void* stream);
+/* LayerNorm-1's affine folded into the packed QKV projection that follows it (decoder.py:53-54:
+ * self_attn(norm1(x)) = xhat (W*gamma)^T + (b + W beta), xhat = the normalised rows): Wf[j,:] = W[j,:]*gamma,
+ * bf[j] = bias[j] + sum_c W[j,c] beta[c].  W [N,K] in w_dtype, Wf [N,K] in wf_dtype (an f32 W may fold straight into a
+ * bf16 Wf: one rounding); leading dimensions ldw, ldwf; bias may be NULL. */
+int capdec_ln_fold_fwd(const void* W, int w_dtype, long ldw, const float* bias, const float* gamma, const float* beta,
+                       int N, int K, void* Wf, int wf_dtype, long ldwf, float* bf, void* stream);
+/* Backward of that pair (the part of decoder.py:189 through norm1 and in_proj) when no gradient flows to the rows:
+ * from G = dY^T xhat [N,K] f32 (the weight-gradient product taken with the normalised rows) and s = column sums of dY [N]:
+ * G <- gamma*G + beta s^T (= d in_proj_weight, in place); dgamma[c] = sum_j W[j,c] G[j,c]; dbeta[c] = sum_j W[j,c] s[j]
+ * (both OVERWRITTEN).  Replaces the product dY W over all rows and the LayerNorm backward pass over them.
+ * partial: capdec_ln_fold_bwd_workspace(N,K) bytes, 16-byte aligned. */
+long capdec_ln_fold_bwd_workspace(int N, int K);
+int capdec_ln_fold_bwd(float* G, long ldg, const float* s, const void* W, int w_dtype, long ldw, const float* gamma, const float* beta,
+                       int N, int K, float* dgamma, float* dbeta, void* partial, void* stream);
 /* Affine gradients of the LayerNorm that capdec_concat_ln_fwd applied (decoder.py:53 on the
  * joined rows of img_text_concat.py:115-123), reading the rows again from img / sos / cap
  * (+ pos) instead of a kept copy of the joined tensor.  dy [(P+1+L)*B, d]; mean/rstd as written

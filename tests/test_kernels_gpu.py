@@ -576,3 +576,35 @@ def test_errors_are_loud():
         ops.gemm(A, B, torch.empty(16, 16, device=DEV))
     with pytest.raises(RuntimeError, match="CPU tensor"):
         ops.gemm(A.cpu(), B.cpu(), torch.empty(16, 16))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("N,K,M", [(2304, 768, 300), (96, 64, 40), (70, 40, 17)])
+def test_ln_fold_pair_matches_autograd(dtype, tol, N, K, M):
+    """LayerNorm affine folded into the Linear after it: forward identity and, from G = dY^T xhat and s = colsum(dY),
+    the gradients autograd gives for the Linear weight and the LayerNorm weight / bias."""
+    W32, bias = rnd(N, K, scale=0.1, seed=81), rnd(N, seed=82)
+    gamma, beta = 1.0 + 0.3 * rnd(K, seed=83), 0.2 * rnd(K, seed=84)
+    W = W32.to(dtype)
+    Wf = torch.full((N, K), float("nan"), device=DEV, dtype=dtype)
+    bf = torch.full((N,), float("nan"), device=DEV)
+    ops.ln_fold_fwd(W, bias, gamma, beta, Wf, bf)
+    close(Wf, W.float() * gamma, tol, "folded weight")
+    close(bf, bias + W.float() @ beta, 2e-5, "folded bias")
+    if dtype == torch.bfloat16:                     # f32 parameter folded straight into a bf16 matrix: one rounding
+        Wf2, bf2 = torch.full((N, K), float("nan"), device=DEV, dtype=dtype), torch.full((N,), float("nan"), device=DEV)
+        ops.ln_fold_fwd(W32, bias, gamma, beta, Wf2, bf2)
+        assert torch.equal(Wf2, (W32 * gamma).to(dtype))
+        close(bf2, bias + W32 @ beta, 2e-5, "folded bias from the f32 parameter")
+    # backward against autograd on y = (xhat*gamma + beta) W^T + b
+    xhat, dY = rnd(M, K, seed=85), rnd(M, N, scale=0.1, seed=86)
+    Wp, g, b = W.float().clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ((xhat * g + b) @ Wp.t() + bias).backward(dY)
+    G = (dY.t() @ xhat).contiguous()
+    s = dY.sum(0).contiguous()
+    dgamma, dbeta = torch.full((K,), float("nan"), device=DEV), torch.full((K,), float("nan"), device=DEV)
+    ws = torch.empty(ops.ln_fold_bwd_workspace(N, K), dtype=torch.uint8, device=DEV)
+    ops.ln_fold_bwd(G, s, W, gamma, beta, dgamma, dbeta, ws)
+    close(G, Wp.grad, 2e-5, "weight gradient")
+    close(dgamma, g.grad, 2e-5, "dgamma")
+    close(dbeta, b.grad, 2e-5, "dbeta")
