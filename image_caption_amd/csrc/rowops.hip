@@ -407,12 +407,13 @@ __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const TW* W, long ldw,
 // s = column sums of dY (the bias gradient) give everything the LayerNorm + Linear pair owes:
 //   dW[j,c] = gamma[c] G[j,c] + beta[c] s[j]        (in place over G)
 //   dgamma[c] = sum_j W[j,c] G[j,c],   dbeta[c] = sum_j W[j,c] s[j]
-// -- no product back to the rows (dY W) and no pass over the rows.  A block owns 32 rows j and writes one partial
+// -- no product back to the rows (dY W) and no pass over the rows.  A block owns FOLD_ROWS rows j and writes one partial
 // row pair [2][K]; ln_bwd_finalize_kernel folds the blocks in a fixed order.
+constexpr int FOLD_ROWS = 8;
 template <typename TW>
 __global__ __launch_bounds__(256) void ln_fold_bwd_kernel(float* G, long ldg, const float* s, const TW* W, long ldw, const float* gamma,
                                                           const float* beta, int N, int K, float* partial) {
-    const int j0 = blockIdx.x * 32, j1 = min(N, j0 + 32);
+    const int j0 = blockIdx.x * FOLD_ROWS, j1 = min(N, j0 + FOLD_ROWS);
     for (int c = threadIdx.x * 4; c < K; c += 1024) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
@@ -708,7 +709,7 @@ extern "C" int capdec_ln_fold_fwd(const void* W, int w_dtype, long ldw, const fl
     return CAPDEC_OK;
 }
 
-extern "C" long capdec_ln_fold_bwd_workspace(int N, int K) { return (long)((N + 31) / 32) * 2 * K * 4; }
+extern "C" long capdec_ln_fold_bwd_workspace(int N, int K) { return (long)((N + FOLD_ROWS - 1) / FOLD_ROWS) * 2 * K * 4; }
 
 extern "C" int capdec_ln_fold_bwd(float* G, long ldg, const float* s, const void* W, int w_dtype, long ldw, const float* gamma, const float* beta,
                                   int N, int K, float* dgamma, float* dbeta, void* partial, void* stream) {
@@ -717,7 +718,7 @@ extern "C" int capdec_ln_fold_bwd(float* G, long ldg, const float* s, const void
     CAPDEC_CHECK(N > 0 && K > 0 && (K % 4) == 0 && (ldg % 4) == 0 && (ldw % al) == 0 && aligned16(G) && aligned16(W) && aligned16(gamma) && aligned16(beta) && aligned16(partial),
                  "ln_fold_bwd: K must be a multiple of 4, rows 16-byte aligned (K=%d, ldg=%ld, ldw=%ld)", K, ldg, ldw);
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (N + 31) / 32;
+    const int nb = (N + FOLD_ROWS - 1) / FOLD_ROWS;
     if (w_dtype == CAPDEC_BF16)
         hipLaunchKernelGGL(ln_fold_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, G, ldg, s, (const bf16_t*)W, ldw, gamma, beta, N, K, (float*)partial);
     else
