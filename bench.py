@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--mask-mode", default="reference")
     ap.add_argument("--activation", default="relu")
     ap.add_argument("--all-rows", action="store_true", help="run every row through the last block (no scored-rows-only skip)")
+    ap.add_argument("--spinup-steps", type=int, default=150, help="untimed steps before the warm-up (device clocks / runtime pools settle)")
+    ap.add_argument("--no-fold-norm1", action="store_true", help="block 0's norm1 applied as written (A/B of folding its affine into in_proj)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-greedy", action="store_true")
     ap.add_argument("--greedy-only", action="store_true", help="skip the training benchmark (profiling of the decoding path)")
@@ -138,7 +140,7 @@ def main():
     B = args.global_batch // world if args.global_batch else args.batch_per_gpu
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     opts = EngineOptions(compute_dtype=cdt, mask_mode=args.mask_mode, activation=args.activation,
-                         scored_rows_only=not args.all_rows)
+                         scored_rows_only=not args.all_rows, fold_norm1=not args.no_fold_norm1)
     if args.vocab_slab:
         opts.vocab_slab = args.vocab_slab
     if args.no_wgrad_stream:
@@ -160,6 +162,13 @@ def main():
     if args.greedy_only:
         print(json.dumps({"greedy": greedy_bench(model, dev, args)}), flush=True)
         return
+    # Device spin-up, untimed and before the W warm-up steps: a process's first ~0.2 s of sustained load contains one or
+    # two 20-35 ms stalls (tools/warmup_probe.py shows them: clock / power-state changes or runtime housekeeping, at a
+    # different step from run to run), which a short warm-up leaves inside the timed steps.  A fixed number of steps, so
+    # that every rank issues the same collectives.
+    for _ in range(args.spinup_steps):
+        trainer.step(inputs, labels)
+    sync()
     for _ in range(args.warmup):
         trainer.step(inputs, labels)
     timer = KernelTimer()
@@ -190,8 +199,8 @@ def main():
                  "head_wgrad_slab": 2.0 * Mh * d * min(slab, V)}
         kernel_names = {"logits_ce_fwd": "gemm_bf16_dma_kernel<false,false,1,2,2,8,3> (EPI_CE_FWD, 256x128 tiles) + ce_finalize_kernel",
                         "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,2,8,3> (EPI_CE_BWD, 256x128 tiles) + colpart_reduce_kernel",
-                        "head_dgrad_slab": "gemm_bf16_dma_kernel<false,true,0,2,4,8,4> (EPI_STD, 256x256 tiles, split-K) + splitk_reduce_kernel",
-                        "head_wgrad_slab": "gemm_bf16_dma_kernel<true,true,0,2,4,8,4> (EPI_STD, 256x256 tiles)"}
+                        "head_dgrad_slab": "gemm_bf16_pipe_kernel<false,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128, split-K) + splitk_reduce_kernel",
+                        "head_wgrad_slab": "gemm_bf16_pipe_kernel<true,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128)"}
         per_kernel = {}
         esz = 2 if args.dtype == "bf16" else 4
         Vp = (V + 127) // 128 * 128
@@ -221,14 +230,15 @@ def main():
                         "whole_step_algorithmic_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 1) if args.n_blocks == 1 and args.patches == 196 else None}
         result = {
             "metric": "train samples/sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup_steps,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"single training step (prefix join + fwd/bwd + CE + Adam) at batch {B} per GPU, "
                                    f"S={args.patches + 33}, d=768, H=8, ff=2048, V=50260, {args.n_blocks} block(s), dropout 0.1",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "mask_mode": args.mask_mode, "activation": args.activation,
-                       "last_block_scored_rows_only": not args.all_rows},
+                       "last_block_scored_rows_only": not args.all_rows, "norm1_folded_into_in_proj": not args.no_fold_norm1},
             "final_loss": round(loss, 4),
             "roofline": roofline,
         }
