@@ -477,3 +477,28 @@ def test_batch_source_resident_and_streamed_feed_identical_training():
     for other in results[1:]:
         for n in results[0]:
             assert torch.equal(results[0][n], other[n]), n
+
+
+@pytest.mark.parametrize("scored,use_pos", [(True, False), (False, True)])
+def test_norm1_fold_is_exact_in_f32(scored, use_pos):
+    """Folding norm1's affine into in_proj (the default when no input gradient is asked for) is algebra, not an
+    approximation: in the f32 mode loss and every gradient agree with the as-written path to rounding."""
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=321)
+    g = torch.Generator().manual_seed(322)
+    sd["norm1.weight"] = 1.0 + 0.3 * torch.randn(sh.d, generator=g)      # away from the (1, 0) a fresh LayerNorm has
+    sd["norm1.bias"] = 0.3 * torch.randn(sh.d, generator=g)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=323)
+    pos = 0.3 * torch.randn(sh.S, sh.d, generator=g).to(DEV) if use_pos else None
+    out = {}
+    for fold in (False, True):
+        m = make_model(sh, sd, F32, scored_rows_only=scored, fold_norm1=fold)
+        m.train()
+        loss, correct = m.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV), pos=pos)
+        loss.backward()
+        out[fold] = (loss.item(), int(correct.item()), {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    assert out[True][1] == out[False][1]
+    for k, ref in out[False][2].items():
+        err = (out[True][2][k] - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item() + 1e-9, (k, err)
