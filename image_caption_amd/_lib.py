@@ -141,6 +141,7 @@ SIGNATURES = {
     "capdec_colsum_workspace": (c_long, [c_long, c_int]),
     "capdec_dropout_bwd_cast": (c_int, [c_void_p, c_long, c_int, Dropout, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_long, c_void_p]),
+    "capdec_colsum_static": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
     "capdec_embed_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),

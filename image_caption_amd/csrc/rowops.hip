@@ -660,6 +660,54 @@ extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, 
     return CAPDEC_OK;
 }
 
+// ------------------------------------------------------------------ column sums without a caller workspace
+// The stripe partials of capdec_colsum live in a fixed array inside the code object instead of a buffer the
+// caller allocates, for callers that cannot allocate (HIP graph capture, serving loops).  Each GPU holds its own
+// copy of the array at its own address; host code only ever uses the address hipGetSymbolAddress returned for
+// the current device, never the array's name.
+constexpr long COLSUM_STATIC_BYTES = CAPDEC_COLSUM_STATIC_BYTES;
+static __device__ __align__(256) unsigned char scratch[COLSUM_STATIC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];            // per device: device address of `scratch`, 0 until first use there
+// address of this device's copy of the array (resolved once per device, with that device current)
+int static_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        capdec_set_error("colsum_static: cannot identify the current device (%s)", hipGetErrorString(e));
+        return CAPDEC_ERR_INVALID;
+    }
+    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            capdec_set_error("colsum_static: hipGetSymbolAddress failed on device %d (%s)", dev, hipGetErrorString(e));
+            return CAPDEC_ERR_LAUNCH;
+        }
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);      // every thread resolves the same address
+    }
+    *out = p;
+    return CAPDEC_OK;
+}
+}  // namespace
+
+extern "C" int capdec_colsum_static(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream) {
+    CAPDEC_CHECK(x && colsum && M >= 0 && N > 0 && ldx >= N, "colsum_static: bad arguments");
+    const long need = capdec_colsum_workspace(M, N);
+    if (need > COLSUM_STATIC_BYTES) {
+        capdec_set_error("colsum_static: M=%ld, N=%d needs %ld bytes of stripe partials, the built-in buffer holds %ld "
+                         "(use capdec_colsum with a caller workspace)", M, N, need, COLSUM_STATIC_BYTES);
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc) return rc;
+    // every partial the fold reads is written by the stripe pass of the same call: nothing has to start at zero
+    return capdec_colsum(x, dtype, M, N, ldx, colsum, ws, COLSUM_STATIC_BYTES, stream);
+}
+
 extern "C" int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
                                  float* out, void* stream) {
     CAPDEC_CHECK(table && ids && out && n >= 0 && d > 0 && (d % 4) == 0, "embed_rows: bad arguments");

@@ -267,6 +267,14 @@ int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
 /* colsum[n] = sum_m x[m,n]  (bias gradients; OVERWRITTEN) */
 int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum,
                   void* workspace, long workspace_bytes, void* stream);
+/* capdec_colsum without a caller workspace.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
+ * stripe partials go to a fixed CAPDEC_COLSUM_STATIC_BYTES array inside the library's code object (one copy per GPU,
+ * held until the process ends); the call allocates nothing and returns CAPDEC_ERR_WORKSPACE when
+ * capdec_colsum_workspace(M, N) exceeds that size.  Results are bit-identical to capdec_colsum.  All calls on one GPU
+ * share the array: calls that overlap in time on the same GPU (different streams) race. */
+#define CAPDEC_COLSUM_STATIC_BYTES (4L << 20)
+int capdec_colsum_static(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream);
 /* rows of a token-embedding table: out[i,:] = table[ids[i],:] (+ pos row if given); out f32 */
 int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
                       float* out, void* stream);
