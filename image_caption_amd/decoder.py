@@ -185,12 +185,10 @@ class TransformerDecoder(nn.Module):
 
 
 def _grad_views(model: TransformerDecoder, keys, device):
-    eng = model.engine
-    out = {}
+    """Fresh gradient tensors for ONE autograd call.  They are owned by that call's graph node, not by the engine:
+    a second forward before the first backward (two losses summed, an evaluation in between) cannot overwrite them."""
     named = model._named()
-    for k in keys:
-        out[k] = eng.buf("grad." + k, named[k].shape, torch.float32, device)
-    return out
+    return {k: torch.empty(named[k].shape, dtype=torch.float32, device=device) for k in keys}
 
 
 class _LogitsFn(torch.autograd.Function):
@@ -205,11 +203,19 @@ class _LogitsFn(torch.autograd.Function):
         ctx.model, ctx.W = model, W
         ctx.need_input = tgt.requires_grad
         src = ("tensor", tgt.detach(), model.prefix_len)
-        return eng.forward_logits(W, src, train=train, step=model._step)
+        out = eng.forward_logits(W, src, train=train, step=model._step)
+        ctx.generation = eng.generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
+        if model.engine.generation != ctx.generation:
+            # the activations this graph needs live in the engine's reusable buffers, and a later forward of the same
+            # model has overwritten them: refuse rather than return the other call's gradients
+            raise RuntimeError("TransformerDecoder.forward was called again (or caption_loss / generate ran) before the backward of "
+                               "an earlier forward: the saved activations of that earlier call are gone. Run backward() before "
+                               "the next forward of the same model, or use caption_loss(), whose gradients are owned per call.")
         keys = model._param_keys()
         grads = _grad_views(model, keys, dlogits.device)
         model.engine.backward_logits(ctx.W, grads, dlogits.contiguous(), need_input_grad=ctx.need_input)
@@ -217,7 +223,7 @@ class _LogitsFn(torch.autograd.Function):
         if ctx.need_input:
             B, S, _ = model.engine._shape
             gin = model.engine.input_grad.view(S, B, -1).clone()
-        return (None, gin) + tuple(grads[k].clone() for k in keys)
+        return (None, gin) + tuple(grads[k] for k in keys)
 
 
 class _CaptionLossFn(torch.autograd.Function):
@@ -271,15 +277,30 @@ class CaptionTrainer:
         self.step_count = 0
         from .dp import GradReducer
         self.reducer = GradReducer(self.store, process_group, bucket_bytes=bucket_bytes, overlap=overlap)
+        if self.reducer.enabled and self.reducer.rank > 0:
+            # every rank draws its own dropout masks: with one shared seed the shards of a global batch would all be
+            # thinned by the same pattern (the engine is built lazily from the options, so this precedes its first use)
+            model.options.dropout_seed = (model.options.dropout_seed + 0x9E3779B1 * self.reducer.rank) & 0x7FFFFFFF
+            if model._engine is not None:
+                model._engine.opt.dropout_seed = model.options.dropout_seed
 
-    def step(self, inputs, labels, pos=None):
+    def step(self, inputs, labels, pos=None, global_batch: Optional[int] = None):
         """One optimisation step on one batch.  Returns (loss_sum [1], correct [1], n_rows)
-        as device tensors (no host synchronisation)."""
+        as device tensors (no host synchronisation).
+
+        Data parallel: each rank passes ITS shard.  The loss is a mean over all rows of the global batch
+        (decoder.py:140), so a rank's gradient is weighted by its share of the rows: pass ``global_batch`` (the
+        number of samples over all ranks) whenever the shards are not equally large; equal shards need nothing."""
         model, eng = self.model, self.model.engine
         self.step_count += 1
         self.reducer.begin()
+        grad_scale = 1.0
+        if global_batch is not None and self.reducer.enabled:
+            # ranks sum their gradients and the optimiser divides by world: local mean * (local rows * world / global rows)
+            grad_scale = labels.shape[0] * self.reducer.world_size / float(global_batch)
         out = eng.loss_and_grads(self.W, self.grads, model._source(inputs), labels, train=model.training,
-                                 step=self.step_count, pos=pos, want_grads=True, on_grad_ready=self.reducer.on_grad_ready)
+                                 step=self.step_count, pos=pos, want_grads=True, grad_scale=grad_scale,
+                                 on_grad_ready=self.reducer.on_grad_ready)
         model._shadow.clear()      # module-mode shadows of the matrices are stale after this update
         st = self.store
 

@@ -40,6 +40,7 @@ class GradReducer:
         self.enabled = bool(dist is not None and dist.is_available() and dist.is_initialized()
                             and (dist.get_world_size(process_group) > 1 or single_ok))
         self.world_size = dist.get_world_size(process_group) if self.enabled else 1
+        self.rank = dist.get_rank(process_group) if self.enabled else 0
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
         self.ready_end = 0       # gradients in g[:ready_end] are final

@@ -187,6 +187,15 @@ def weights_from_store(store: ParamStore) -> _Weights:
     return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows)
 
 
+def _seqfirst_addressable(t: torch.Tensor) -> bool:
+    """Whether capdec_seqfirst_ln_fwd can read the [S, B, d] view as it lies: f32 / bf16, unit stride along d,
+    every row 16-byte aligned."""
+    if t.dtype not in (torch.float32, torch.bfloat16) or t.stride(2) != 1 or t.data_ptr() % 16:
+        return False
+    per16 = 4 if t.dtype == torch.float32 else 8
+    return all(st % per16 == 0 for st in t.stride()[:2])
+
+
 class DecoderEngine:
     def __init__(self, geo: ModelGeometry, options: Optional[EngineOptions] = None):
         self.geo = geo
@@ -203,6 +212,7 @@ class DecoderEngine:
         self.timer: Optional[KernelTimer] = None
         self._side: Optional[torch.cuda.Stream] = None
         self._side_used = False
+        self.generation = 0          # bumped by every forward: the saved activations belong to the latest one only
 
     def _span(self, name: str):
         return self.timer.span(name) if self.timer is not None else contextlib.nullcontext()
@@ -331,6 +341,7 @@ class DecoderEngine:
             raise ValueError("prefix_causal masking needs the prefix length")
         dev = source[1].device
         M = S * B
+        self.generation += 1
         self.saved = [None] * geo.n_blocks
         nb = geo.n_blocks
         last_q0 = (S - L_scored) if (L_scored is not None and self.opt.scored_rows_only) else 0
@@ -364,19 +375,22 @@ class DecoderEngine:
                     ops.concat_ln_fwd(img, sos, cap, g1, b1, pos=pos, x_out=x0,
                                       x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
                     concat_src = ("concat", img, sos, cap, pos)
-                elif (tgt.dtype in (torch.float32, torch.bfloat16) and tgt.stride(2) == 1 and tgt.data_ptr() % 16 == 0
-                      and all(st % (4 if tgt.dtype == torch.float32 else 8) == 0 for st in tgt.stride()[:2])
-                      and (pos is not None or not keep_joined or tgt.dtype != torch.float32 or not tgt.is_contiguous())):
-                    # a strided seq-first slice (dataset[:, i:j, :]) is normalised where it lies: no contiguous copy
-                    x0 = self.buf("x0", (M, d), torch.float32, dev)
-                    ops.seqfirst_ln_fwd(tgt, g1, b1, pos=pos, x_out=x0,
-                                        x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
-                    concat_src = ("seqfirst", tgt, pos)
                 else:
-                    x0 = tgt.reshape(M, d)
-                    if x0.dtype != torch.float32 or not x0.is_contiguous():
-                        x0 = x0.float().contiguous()
-                    ops.ln_fwd(x0, g1, b1, h1, mean1, rstd1)
+                    # a strided seq-first slice (dataset[:, i:j, :]) is normalised where it lies, without a contiguous
+                    # copy; anything the strided kernel cannot address (other dtypes, a non-unit inner stride, rows that
+                    # are not 16-byte aligned) is first brought to a contiguous f32 tensor, which it can
+                    if not _seqfirst_addressable(tgt):
+                        tgt = tgt.float().contiguous()
+                        if not _seqfirst_addressable(tgt):       # an f32 contiguous view at an odd offset
+                            tgt = tgt.clone()
+                    if pos is not None or not keep_joined or tgt.dtype != torch.float32 or not tgt.is_contiguous():
+                        x0 = self.buf("x0", (M, d), torch.float32, dev)
+                        ops.seqfirst_ln_fwd(tgt, g1, b1, pos=pos, x_out=x0,
+                                            x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
+                        concat_src = ("seqfirst", tgt, pos)
+                    else:
+                        x0 = tgt.reshape(M, d)                   # already the joined f32 rows: normalise them in place
+                        ops.ln_fwd(x0, g1, b1, h1, mean1, rstd1)
                 x = self._block_fwd(0, W, x0, B, S, q0, train, step, dev, h1_ready=(h1, mean1, rstd1), in_proj=in_proj)
                 self.saved[0]["concat_src"] = concat_src
             else:
