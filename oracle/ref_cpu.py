@@ -139,13 +139,19 @@ def block_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], nhead: int, mask:
                   activation: str = "relu", drop_p: float = 0.0,
                   keep: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """decoder.py:53-63.  ``keep`` holds explicit dropout keep-masks:
-    "attn" [B,H,S,S], "resid1" [S,B,d], "hidden" [S,B,ff], "resid2" [S,B,d]."""
+    "attn" [B,H,S,S], "resid1" [S,B,d], "hidden" [S,B,ff], "resid2" [S,B,d].
+    "relu_gate" [S,B,ff] (1 = open), a checker's device: the ReLU's on/off pattern is taken from the caller
+    instead of the sign of the pre-activation, to compare with a reduced-precision forward whose pre-activations
+    near zero fall on the other side (the comparison then measures everything but those flips)."""
     keep = keep or {}
     h = layer_norm(x, p["norm1.weight"], p["norm1.bias"])
     a = attention(h, p, nhead, mask, keep.get("attn"), drop_p)
     x = x + _drop(a, keep.get("resid1"), drop_p)
     h = layer_norm(x, p["norm2.weight"], p["norm2.bias"])
-    h = _activation(h @ p["linear1.weight"].t() + p["linear1.bias"], activation)
+    if keep.get("relu_gate") is not None and activation == "relu":
+        h = (h @ p["linear1.weight"].t() + p["linear1.bias"]) * keep["relu_gate"].to(h.dtype)
+    else:
+        h = _activation(h @ p["linear1.weight"].t() + p["linear1.bias"], activation)
     h = _drop(h, keep.get("hidden"), drop_p)
     h = h @ p["linear2.weight"].t() + p["linear2.bias"]
     return x + _drop(h, keep.get("resid2"), drop_p)

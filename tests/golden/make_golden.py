@@ -18,6 +18,10 @@ Files written next to this script:
   mask.npz        create_caption_mask known answers
   composed.npz    build-defined modes obtained by COMPOSING the reference class:
                   prefix-causal mask, two stacked blocks, greedy decoding
+  default_b8_grads.npz  the same default-shape step: every small gradient in full and a
+                  strided slice of every matrix gradient (slicing: helpers.grad_slice)
+  train_loop.npz  the per-split loss / accuracy history logged by the reference's own
+                  train_decoder (decoder.py:96-216) on a small seeded dataset
 """
 import os
 import sys
@@ -37,8 +41,16 @@ from helpers import DEFAULT_B8, TINY
 REF = "/root/reference"
 
 
+WANDB_LOG = []      # what the reference hands to wandb.log
+
+
 def import_reference():
-    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    # wandb is not installed here; the reference only uses init / log / finish, none of which carries arithmetic:
+    # log records its argument, the other two do nothing
+    w = sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    w.init = lambda *a, **k: None
+    w.finish = lambda *a, **k: None
+    w.log = lambda rec, *a, **k: WANDB_LOG.append(dict(rec))
     sys.path.insert(0, REF)
     import decoder as ref_decoder            # noqa: E402  (the reference's file)
     sys.path.remove(REF)
@@ -116,6 +128,24 @@ def gen_default(ref):
     d["grad.output_projection.weight_rows"] = m.output_projection.weight.grad[::1009].numpy()
     np.savez_compressed(os.path.join(HERE, "default_b8.npz"), **d)
     print("default_b8: loss", loss.item(), "correct", correct, "absmax", d["logit_absmax"])
+    dg = {"grad." + k: helpers.grad_slice(p.grad.detach()).numpy() for k, p in m.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "default_b8_grads.npz"), **dg)
+
+
+def gen_train_loop(ref):
+    """The reference's own train_decoder on CPU: what it logs per split and epoch."""
+    cfg, data, seed = helpers.train_loop_case()
+    rcfg = sys.modules["config"].DecoderConfig(**cfg, device="cpu")       # the reference's config class
+    del WANDB_LOG[:]
+    torch.manual_seed(seed)                  # the model is initialised from the global generator (decoder.py:125-132)
+    ref.train_decoder(data, rcfg)
+    hist = [r for r in WANDB_LOG if "epoch" in r]
+    d = {"loss": np.array([[v for k, v in r.items() if k.endswith("_loss")][0] for r in hist], dtype=np.float64),
+         "accuracy": np.array([[v for k, v in r.items() if k.endswith("_accuracy")][0] for r in hist], dtype=np.float64),
+         "split": np.array([[k[:-5] for k in r if k.endswith("_loss")][0] for r in hist]),
+         "epoch": np.array([r["epoch"] for r in hist], dtype=np.int64)}
+    np.savez_compressed(os.path.join(HERE, "train_loop.npz"), **d)
+    print("train_loop:", list(zip(d["split"], d["loss"].round(4), d["accuracy"].round(2))))
 
 
 def gen_mask(ref):
@@ -210,6 +240,7 @@ if __name__ == "__main__":
     gen_default(ref)
     gen_mask(ref)
     gen_composed(ref)
+    gen_train_loop(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -93,3 +93,28 @@ def make_embeddings(sh: Shape, seed: int):
 def make_token_table(sh: Shape, seed: int):
     gen = torch.Generator().manual_seed(seed)
     return torch.randn(sh.vocab, sh.d, generator=gen)
+
+
+def grad_slice(g: torch.Tensor) -> torch.Tensor:
+    """What the default-shape fixture keeps of a gradient: vectors in full, matrices every 13th row and 7th
+    column (the vocabulary matrix every 211th row and 3rd column)."""
+    if g.dim() == 1:
+        return g.clone()
+    if g.shape[0] > 10000:
+        return g[::211, ::3].clone()
+    return g[::13, ::7].clone()
+
+
+def train_loop_case():
+    """Configuration, processed dataset and model seed of the train_decoder fixture: 40 samples -> 36 train
+    (five batches, the last one ragged) + 4 test; labels drawn from six token ids so that token accuracy
+    leaves zero within a few steps.  The vocabulary is the 50260 the reference's loop hard-codes (decoder.py:131)."""
+    cfg = dict(d_model=64, nhead=2, num_layers=6, dim_feedforward=128, dropout=0.0, batch_size=8, learning_rate=2e-3,
+               num_epochs=3, weight_decay=0.01, max_caption_length=8)
+    gen = torch.Generator().manual_seed(4321)
+    N, S, L = 40, 21, 8
+    tokens = torch.tensor([17, 4242, 9001, 31337, 50257, 50259])
+    labels = tokens[torch.randint(0, len(tokens), (N, L), generator=gen)]
+    data = {"decoder_inputs": torch.randn(S, N, 64, generator=gen),
+            "caption_input_ids": torch.roll(labels, 1, dims=1), "caption_labels": labels}
+    return cfg, data, 1234

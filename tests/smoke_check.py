@@ -36,10 +36,10 @@ def run():
     for k, p in m.named_parameters():
         a, b = p.grad.cpu().flatten().double(), leaf[k].grad.flatten().double()
         c = float(a @ b / (a.norm() * b.norm() + 1e-30))
-        # 0.998: at this 64-wide shape the bf16 gradients of the MLP tensors scatter over 0.9976-0.9993 from seed to seed
-        # (measured against the f32 mode, with norm1 applied as written or folded into in_proj alike); the golden-vector
-        # tests at the reference's shapes hold 0.999
-        assert c >= 0.998, (k, c)
+        # 0.999, except for the tensors read straight through the ReLU's on/off pattern: bf16 flips the gates of the
+        # pre-activations nearest zero, which alone puts those four tensors at 0.9976-0.9993 at this 64-wide shape
+        gated = k.endswith(("linear1.weight", "linear1.bias", "norm2.weight", "norm2.bias"))
+        assert c >= (0.9975 if gated else 0.999), (k, c)
 
     m32 = TransformerDecoder(sh.d, sh.nhead, 6, sh.ff, 0.0, sh.vocab, options=EngineOptions(compute_dtype=torch.float32))
     m32.load_state_dict(sd)

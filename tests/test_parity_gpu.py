@@ -44,14 +44,26 @@ def cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def check_grads(model, ref_grads, dtype, bar=0.999):
+# Tensors whose gradient passes through the ReLU's on/off pattern before anything averages it.  A bf16 forward puts
+# the pre-activations closest to zero on the other side of it (0.075 % of them at the default shape), and each flipped
+# gate moves a whole term of these sums: 4 % relative error, cosine 0.9989-0.9993, in any bf16 formulation, while every
+# other tensor stays above 0.9999 (measured: tools/grad_cosines.py; handing the oracle the same gates removes it:
+# test_bf16_gradients_with_the_same_relu_gates).
+RELU_GATED = ("linear1.weight", "linear1.bias", "norm2.weight", "norm2.bias")
+
+
+def grad_bar(key, activation="relu", gated_bar=0.9985):
+    return gated_bar if activation == "relu" and key.endswith(RELU_GATED) else 0.999
+
+
+def check_grads(model, ref_grads, dtype, activation="relu", gated_bar=0.9985):
     for k, ref in ref_grads.items():
         g = dict(model.named_parameters())[k].grad.cpu()
         ref = torch.as_tensor(ref)
         if dtype == F32:
             assert (g - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-9, k
         else:
-            assert cos(g, ref) >= bar, (k, cos(g, ref))
+            assert cos(g, ref) >= grad_bar(k, activation, gated_bar), (k, cos(g, ref))
 
 
 # ---------------------------------------------------------------------------- golden: tiny, full tensors
@@ -119,6 +131,42 @@ def test_default_b8_golden(dtype, slab):
     else:
         assert cos(rows, ref_rows) >= 0.999
         assert cos(named["self_attn.in_proj_bias"].grad.cpu(), torch.from_numpy(g["grad.self_attn.in_proj_bias"])) >= 0.999
+    # every gradient element-wise (vectors in full, matrices on a strided grid): a permutation or a sign flip inside a
+    # tensor keeps its norm but not these
+    gg = golden("default_b8_grads.npz")
+    for k in ref_cpu.PARAM_KEYS:
+        got = helpers.grad_slice(named[k].grad).cpu()
+        ref = torch.from_numpy(gg["grad." + k])
+        assert got.shape == ref.shape, k
+        if dtype == F32:
+            assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-12, k
+        else:
+            assert cos(got, ref) >= grad_bar(k), (k, cos(got, ref))
+
+
+def test_bf16_gradients_with_the_same_relu_gates():
+    """Default shape, batch 8, bf16: once the oracle is handed the on/off pattern of the ReLU that the bf16 forward
+    produced, EVERY gradient reaches cosine 0.999 -- what separates the gate-downstream tensors from the f32 result is
+    the few pre-activations whose sign bf16 changes, nothing else."""
+    sh = DEFAULT_B8
+    sd = helpers.make_state_dict(sh, seed=303)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=404)
+    model = make_model(sh, sd, BF16, scored_rows_only=False)
+    model.train()
+    loss, _ = model.caption_loss((img.to(DEV), sos.to(DEV), cap.to(DEV)), labels.to(DEV))
+    loss.backward()
+    gate = (model.engine.saved[0]["a1"] != 0).reshape(sh.S, sh.B, sh.ff).cpu()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    blocks, head = ref_cpu.split_params(leaf)
+    x = ref_cpu.concat_prefix(img, sos, cap)
+    h = ref_cpu.decoder_hidden(x, blocks, sh.nhead, keep=[{"relu_gate": gate}])
+    tail = h[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]       # the scored rows
+    lo, _, _ = ref_cpu.caption_loss(tail, labels, sh.L)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 1e-2 * lo.item()
+    named = dict(model.named_parameters())
+    for k in leaf:
+        assert cos(named[k].grad.cpu(), leaf[k].grad) >= 0.999, (k, cos(named[k].grad.cpu(), leaf[k].grad))
 
 
 # ---------------------------------------------------------------------------- oracle: build-defined modes
@@ -158,10 +206,8 @@ def test_modes_vs_oracle(dtype, mask_mode, activation, n_blocks, use_pos, scored
     for i in range(n_blocks):
         for k in ref_cpu.BLOCK_KEYS:
             ref_grads[block_key(i, k, n_blocks)] = leaf[i][k].grad
-    # bf16 bar 0.998 here, 0.999 on the golden vectors: at this 64-wide shape the gradient of linear1.weight sits at
-    # 0.99901 (norm1 applied as written) / 0.998995 (norm1's affine folded into in_proj, the default) for the
-    # prefix-causal case's seed -- bf16 rounding of the ReLU gate's operands, the same in both formulations
-    check_grads(model, ref_grads, dtype, bar=0.998)
+    # bf16: 0.999 per tensor, except those read straight through the ReLU's gates (0.998 at this 64-wide shape)
+    check_grads(model, ref_grads, dtype, activation=activation, gated_bar=0.998)
 
 
 def test_composed_golden():
@@ -426,6 +472,40 @@ def test_state_dict_and_init_match_reference_layout():
         m(torch.zeros(21, 2, 64), None)
 
 
+def test_create_caption_mask_past_12288_columns():
+    """decoder.py:33-37 at a length where the mask is not all zero: columns from 16*768 on are causal."""
+    g = golden("mask.npz")
+    m = TransformerDecoder(16, 2, 6, 16, 0.0, 11).to(DEV)
+    n = int(g["big_len"])
+    mask = m.create_caption_mask(n)
+    assert mask.shape == (n, n) and mask.dtype == torch.float32
+    assert torch.equal(mask[-12:, -12:].cpu(), torch.from_numpy(g["big_corner"]))
+    assert int(torch.isinf(mask).sum().item()) == int(g["big_neginf_count"])
+    assert int((mask[:, :12288] != 0).sum().item()) == int(g["big_left_nonzero"])
+    assert bool((mask[torch.isinf(mask)] < 0).all())
+    assert torch.equal(torch.unique(m.create_caption_mask(229)).cpu(), torch.from_numpy(g["m229_unique"]))
+
+
+def test_train_decoder_reproduces_the_reference_history():
+    """train_decoder against what the reference's own loop logged on the same seeded data (decoder.py:96-216):
+    90/10 split by position, both splits trained, ragged last batch, mean of per-batch mean losses, token accuracy."""
+    from image_caption_amd.config import DecoderConfig
+    from image_caption_amd.decoder import train_decoder
+    g = golden("train_loop.npz")
+    cfg_kw, data, seed = helpers.train_loop_case()
+    cfg = DecoderConfig(**cfg_kw, device="cuda")
+    torch.manual_seed(seed)                     # after the config: constructing it seeds torch (config.py:41)
+    logs = []
+    model = train_decoder(data, cfg, options=EngineOptions(compute_dtype=F32), log=lambda *a: None, logger=logs.append)
+    hist = model.training_history
+    assert len(hist) == len(g["loss"]) == 2 * cfg.num_epochs
+    for rec, split, epoch, loss, acc in zip(hist, g["split"], g["epoch"], g["loss"], g["accuracy"]):
+        assert rec["epoch"] == int(epoch)
+        assert abs(rec[f"{split}_loss"] - float(loss)) <= 1e-4 * float(loss), (split, epoch, rec, float(loss))
+        assert abs(rec[f"{split}_accuracy"] - float(acc)) < 1e-9, (split, epoch, rec, float(acc))
+    assert float(g["accuracy"].max()) > 10.0    # the fixture's accuracy is not the trivial zero
+
+
 def test_train_decoder_loop():
     from image_caption_amd.config import DecoderConfig
     from image_caption_amd.decoder import train_decoder
@@ -502,3 +582,72 @@ def test_norm1_fold_is_exact_in_f32(scored, use_pos):
     for k, ref in out[False][2].items():
         err = (out[True][2][k] - ref).abs().max().item()
         assert err <= 2e-5 * ref.abs().max().item() + 1e-9, (k, err)
+
+
+# ---------------------------------------------------------------------------- autograd state is per call
+def test_two_forwards_before_one_backward():
+    """The reference module may be called twice before backward (two losses summed, an evaluation in between).
+    caption_loss owns its gradients per call; forward() detects that its saved activations were overwritten."""
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=141)
+    a = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=252)]
+    b = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=253)]
+    singles = []
+    for img, sos, cap, labels in (a, b):
+        m = make_model(sh, sd, F32)
+        m.train()
+        loss, _ = m.caption_loss((img, sos, cap), labels)
+        loss.backward()
+        singles.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    m = make_model(sh, sd, F32)
+    m.train()
+    la, _ = m.caption_loss((a[0], a[1], a[2]), a[3])
+    lb, _ = m.caption_loss((b[0], b[1], b[2]), b[3])
+    with torch.no_grad():
+        m.caption_loss((a[0], a[1], a[2]), a[3])            # an evaluation between forward and backward
+    (la + 2.0 * lb).backward()
+    for k, p in m.named_parameters():
+        want = singles[0][k] + 2.0 * singles[1][k]
+        assert (p.grad - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-10, k
+    # forward(): the second call reuses the engine's activation buffers, so the first graph must refuse
+    x1 = ref_cpu.concat_prefix(*[t.cpu() for t in a[:3]]).to(DEV)
+    x2 = ref_cpu.concat_prefix(*[t.cpu() for t in b[:3]]).to(DEV)
+    y1 = m(x1, x1)
+    y2 = m(x2, x2)
+    with pytest.raises(RuntimeError, match="before the backward"):
+        y1.sum().backward()
+    m.zero_grad()
+    y2.sum().backward()                                    # the latest forward's graph is intact
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize("layout", ["fp16", "inner_stride", "odd_offset"])
+def test_positional_rows_survive_every_input_layout(layout):
+    """A joined input the strided LayerNorm kernel cannot address as it lies (fp16, a non-unit inner stride, rows
+    that are not 16-byte aligned) takes a conversion first -- and must still get its positional rows."""
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=151)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=262)
+    pos = (0.3 * torch.randn(sh.S, sh.d, generator=torch.Generator().manual_seed(9))).to(DEV)
+    x = ref_cpu.concat_prefix(img, sos, cap).half().float().to(DEV)        # exactly representable in fp16
+    if layout == "fp16":
+        odd = x.half()
+    elif layout == "inner_stride":
+        odd = torch.empty(sh.S, sh.B, sh.d * 2, device=DEV)[..., ::2]
+        odd.copy_(x)
+        assert odd.stride(2) == 2
+    else:
+        flat = torch.empty(x.numel() + 1, device=DEV)
+        odd = flat[1:].view(sh.S, sh.B, sh.d)
+        odd.copy_(x)
+        assert odd.data_ptr() % 16 != 0
+    m = make_model(sh, sd, F32)
+    m.train()
+    want, _ = m.caption_loss(x, labels.to(DEV), pos=pos)
+    got, _ = m.caption_loss(odd, labels.to(DEV), pos=pos)
+    none, _ = m.caption_loss(odd, labels.to(DEV))
+    assert got.item() == want.item()
+    assert abs(none.item() - want.item()) > 1e-4           # the positional term is not a no-op on this input
+    lg = ref_cpu.decoder_forward(x.cpu() + pos.cpu().unsqueeze(1), *ref_cpu.split_params(sd), sh.nhead)
+    lo, _, _ = ref_cpu.caption_loss(lg, labels, sh.L)
+    assert abs(got.item() - lo.item()) <= 1e-5 * lo.item()
