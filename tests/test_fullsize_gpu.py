@@ -1,0 +1,208 @@
+"""Parity at the sizes the benchmark runs (the kernels the dispatcher picks there are not the ones small shapes reach):
+  * the vocabulary-sized products at 8192 scored rows (batch 256) against torch f32 products of the same operands;
+  * one training step at batch 256, config.py defaults: bf16 and f32 modes against the CPU oracle and each other;
+  * the scaled configuration (12 blocks, 257 patches, prefix-causal mask) at d=768 against the CPU oracle;
+  * KV-cached greedy decoding of 4096 images, whose first 8 are the reference-composed fixture's.
+Tolerances as in test_parity_gpu.py (f32: loss 1e-5, grads 1e-4 of the tensor's max; bf16: loss 1e-2, cosine 0.999,
+0.9985 for the four tensors read straight through the ReLU's gates)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers  # noqa: E402
+from helpers import DEFAULT_B8, GOLDEN_DIR, Shape  # noqa: E402
+from image_caption_amd import ops  # noqa: E402
+from image_caption_amd.decoder import TransformerDecoder  # noqa: E402
+from image_caption_amd.engine import EngineOptions, block_key  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from test_parity_gpu import cos, grad_bar, make_model  # noqa: E402
+
+DEV = "cuda"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def close(a, b, tol, what):
+    scale = b.abs().max().item() + 1e-12
+    err = (a.float() - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+# ---------------------------------------------------------------------------- the head's four launches at batch 256
+def test_head_products_at_batch_256():
+    """logits + CE forward with kept numerators, d(logits) from them, head wgrad and split-K dgrad at
+    M = 8192, V = 50260, d = 768 -- the launches that make up 60 % of the benchmark step."""
+    Bb, L, V, d = 256, 32, 50260, 768
+    M = Bb * L
+    g = torch.Generator(device=DEV).manual_seed(5)
+    h = torch.randn(M, d, device=DEV, generator=g).to(BF16)
+    Vp = (V + 127) // 128 * 128
+    Wfull = torch.zeros(Vp, d, device=DEV, dtype=BF16)             # zero rows past V, as in the flat parameter store
+    Wfull[:V] = (torch.randn(V, d, device=DEV, generator=g) * 0.05).to(BF16)
+    W = Wfull[:V]
+    b = torch.randn(V, device=DEV, generator=g) * 0.05
+    labels = torch.randint(0, V, (Bb, L), device=DEV, generator=g)
+    z = h.float() @ W.float().t() + b                              # 1.65 GB of f32 logits: the thing the kernels never store
+    lab_rows = labels.t().reshape(-1)
+    ref_lse = torch.logsumexp(z, 1)
+    ref_loss = (ref_lse - z.gather(1, lab_rows[:, None])[:, 0]).sum()
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    lse, amax = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=BF16)
+    ops.logits_ce_fwd(h, W, b, labels, Bb, L, lse, amax, ls, cr, ws, probs=dl)
+    close(lse, ref_lse, 1e-4, "lse")
+    assert abs(ls.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
+    top2 = z.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-3                     # the operands are the same bf16 values: only f32 summation order differs
+    assert torch.equal(amax.long()[decided], z.argmax(1)[decided]) and decided.float().mean().item() > 0.9
+    assert int(cr.item()) == int((amax.long() == lab_rows).sum().item())
+    assert not bool(torch.isnan(dl.float()).any())
+    dbias = torch.full((V,), float("nan"), device=DEV)
+    bws = torch.empty(ops.logits_ce_bwd_workspace(M, V), dtype=torch.uint8, device=DEV)
+    ops.logits_ce_bwd_from_probs(dl, V, labels, Bb, L, lse, 1.0 / M, ws, dbias, bws)
+    ref_dl = torch.softmax(z, 1)
+    ref_dl[torch.arange(M, device=DEV), lab_rows] -= 1.0
+    ref_dl /= M
+    del z
+    close(dl[:, :V], ref_dl, 1e-2, "d(logits)")
+    assert float(dl[:, V:].float().abs().max()) == 0.0
+    close(dbias, ref_dl.sum(0), 1e-2, "d(bias)")
+    del ref_dl
+    dlf = dl.float()                                               # the products below are checked on the bf16 operand they consume
+    gW = torch.full((V, d), float("nan"), device=DEV)
+    ops.gemm(dl, h, gW, M=V, N=d, K=M, a_kmajor=True, b_kmajor=True)
+    close(gW, dlf[:, :V].t() @ h.float(), 2e-3, "head weight gradient")
+    hws = torch.empty(8 * M * d * 4, dtype=torch.uint8, device=DEV)
+    dH = torch.full((M, d), float("nan"), device=DEV)
+    ops.gemm(dl, Wfull, dH, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws)
+    ref_dH = dlf @ Wfull.float()
+    close(dH, ref_dH, 2e-3, "head input gradient (split-K)")
+    dH2 = ref_dH.clone()
+    ops.gemm(dl, Wfull, dH2, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws, accumulate=True)
+    close(dH2, 2 * ref_dH, 2e-3, "head input gradient, accumulated")
+
+
+# ---------------------------------------------------------------------------- configs[1]: one step at batch 256
+def test_default_config_batch_256_step():
+    sh = Shape(B=256)
+    sd = helpers.make_state_dict(sh, seed=303)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=2560)
+    # oracle: forward only, vocabulary projection on the 32 scored rows (1.6 GB of f32 logits instead of 11.8 GB)
+    with torch.no_grad():
+        blocks, head = ref_cpu.split_params(sd)
+        hid = ref_cpu.decoder_hidden(ref_cpu.concat_prefix(img, sos, cap), blocks, sh.nhead)
+        tail = hid[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]
+        ref_loss, ref_correct, _ = ref_cpu.caption_loss(tail, labels, sh.L)
+        del hid, tail
+    dev_in = (img.to(DEV), sos.to(DEV), cap.to(DEV))
+    grads = {}
+    for dtype in (F32, BF16):
+        m = make_model(sh, sd, dtype)
+        m.train()
+        loss, correct = m.caption_loss(dev_in, labels.to(DEV))
+        loss.backward()
+        assert abs(loss.item() - ref_loss.item()) <= (1e-5 if dtype == F32 else 1e-2) * ref_loss.item(), (dtype, loss.item(), ref_loss.item())
+        # hits among 8192 rows with random labels: a handful at most; bf16 may move one or two near-ties
+        assert abs(int(correct.item()) - ref_correct) <= (0 if dtype == F32 else 3)
+        assert m.engine.last_from_probs and m.engine.last_slab >= sh.vocab      # the whole-vocabulary kept-numerator path ran
+        grads[dtype] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        del m
+    for k in ref_cpu.PARAM_KEYS:
+        c = cos(grads[BF16][k], grads[F32][k])
+        assert c >= grad_bar(k), (k, c)
+
+
+# ---------------------------------------------------------------------------- configs[4]: 12 blocks, 257 patches, S = 290
+@pytest.mark.parametrize("activation", ["relu", "gelu"])
+def test_scaled_config_12_blocks(activation):
+    sh = Shape(P=257, B=2)
+    nb = 12
+    sds = [helpers.make_state_dict(sh, seed=1200 + i) for i in range(nb)]
+    full = dict(sds[0])
+    for i in range(1, nb):
+        for k in ref_cpu.BLOCK_KEYS:
+            full[block_key(i, k, nb)] = sds[i][k]
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=1299)
+    dev_in = (img.to(DEV), sos.to(DEV), cap.to(DEV))
+    named = {}
+    gates = None
+    for dtype in (F32, BF16):
+        m = make_model(sh, full, dtype, n_blocks=nb, mask_mode="prefix_causal", activation=activation)
+        m.train()
+        loss, correct = m.caption_loss(dev_in, labels.to(DEV))
+        loss.backward()
+        named[dtype] = (loss.item(), int(correct.item()), {k: p.grad.cpu() for k, p in m.named_parameters()})
+        if dtype == F32 and activation == "relu":
+            # 14 million ReLU gates: a handful of pre-activations lie within f32 summation-order noise of zero, and each
+            # one that lands on the other side moves a whole term of the gradients read through it (1e-3 of a tensor's
+            # max for one flip).  The oracle therefore takes the f32 run's on/off pattern (rows the last block did not
+            # compute do not reach the loss: any pattern serves there); the loss and every other tensor need no such help
+            gates = []
+            for i in range(nb):
+                a1 = m.engine.saved[i]["a1"]
+                gate = torch.ones(sh.S * sh.B, sh.ff)
+                gate[sh.S * sh.B - a1.shape[0]:] = (a1 != 0).float().cpu()
+                gates.append({"relu_gate": gate.reshape(sh.S, sh.B, sh.ff)})
+        del m
+    leaf = [{k: sds[i][k].clone().requires_grad_(True) for k in ref_cpu.BLOCK_KEYS} for i in range(nb)]
+    head = {k: sds[0][k].clone().requires_grad_(True) for k in ref_cpu.PARAM_KEYS[12:]}
+    x = ref_cpu.concat_prefix(img, sos, cap)
+    hid = ref_cpu.decoder_hidden(x, leaf, sh.nhead, mask_mode="prefix_causal", prefix_len=sh.P, activation=activation, keep=gates)
+    tail = hid[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]
+    lo, co, _ = ref_cpu.caption_loss(tail, labels, sh.L)
+    lo.backward()
+    ref_grads = {k: head[k].grad for k in head}
+    for i in range(nb):
+        for k in ref_cpu.BLOCK_KEYS:
+            ref_grads[block_key(i, k, nb)] = leaf[i][k].grad
+    for dtype in (F32, BF16):
+        loss, correct, grads = named[dtype]
+        assert abs(loss - lo.item()) <= (1e-5 if dtype == F32 else 1e-2) * lo.item(), (dtype, loss, lo.item())
+        if dtype == F32:
+            assert correct == co
+        for k, ref in ref_grads.items():
+            g = grads[k]
+            if dtype == F32:
+                assert (g - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-10, k
+            else:
+                assert cos(g, ref) >= grad_bar(k, activation), (k, cos(g, ref))
+
+
+# ---------------------------------------------------------------------------- configs[3]: 4096 images, greedy, KV cache
+def test_greedy_4096_images():
+    """The first 8 of the 4096 images are those of the fixture composed from the reference class: sequences are
+    independent, so their captions must be the fixture's whatever else is in the batch."""
+    g = np.load(os.path.join(GOLDEN_DIR, "composed.npz"))
+    sh = DEFAULT_B8
+    sd = helpers.make_state_dict(sh, seed=1212, head_gain=6.0)
+    img8, sos8, _, _ = helpers.make_embeddings(sh, seed=1313)
+    emb = helpers.make_token_table(sh, seed=1414).to(DEV)
+    n = 4096
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    img = torch.randn(n, sh.P, sh.d, device=DEV, generator=gen)
+    sos = torch.randn(n, 1, sh.d, device=DEV, generator=gen)
+    img[:8], sos[:8] = img8.to(DEV), sos8.to(DEV)
+    ref_ids = torch.from_numpy(g["greedy_default_ids"])
+    ref_margins = torch.from_numpy(g["greedy_default_margins"])
+    m32 = make_model(sh, sd, F32)
+    m32.eval()
+    ids = m32.generate(img, sos, emb, max_len=sh.L).cpu()
+    assert torch.equal(ids[:8], ref_ids)
+    assert ids.unique().numel() > 100                       # margin-checked weights: captions differ from image to image
+    del m32
+    mb = make_model(sh, sd, BF16)
+    mb.eval()
+    idb = mb.generate(img, sos, emb, max_len=sh.L).cpu()
+    safe = (ref_margins > 0.25).cumprod(dim=1).bool()
+    assert torch.equal(idb[:8][safe], ref_ids[safe])
+    # over all 4096 images: the first token (no earlier decision to inherit a difference from) agrees with the f32
+    # mode for all but the near-ties, and bf16 captions are as varied as the f32 ones
+    first = (idb[:, 0] == ids[:, 0]).float().mean().item()
+    print(f"bf16 vs f32 greedy: first token {first:.4f}, all tokens {(idb == ids).float().mean().item():.4f}, "
+          f"distinct tokens {idb.unique().numel()} / {ids.unique().numel()}")
+    assert first >= 0.9
+    assert idb.unique().numel() > 100
