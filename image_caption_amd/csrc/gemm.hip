@@ -1329,7 +1329,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             else if (a.K >= 2048) kern = KERN_WIDE;
         }
         if (g_gemm_mode == 1) kern = KERN_REG;
-        else if (g_gemm_mode == 5 && ring_ok && EPI == EPI_STD) kern = KERN_WIDE;
+        else if (g_gemm_mode == 5 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_WIDE;
         else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
         else if (g_gemm_mode == 7 && ring_ok && !any_km) kern = KERN_TALLP;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
@@ -1386,6 +1386,8 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
                 else if (a.a_kmajor) CAPDEC_RING_LAUNCH(true, false, 2, 4, 8, 4, wide_tiles);
                 else if (a.b_kmajor) CAPDEC_RING_LAUNCH(false, true, 2, 4, 8, 4, wide_tiles);
                 else CAPDEC_RING_LAUNCH(false, false, 2, 4, 8, 4, wide_tiles);
+            } else {
+                CAPDEC_RING_LAUNCH(false, false, 2, 4, 8, 4, wide_tiles);
             }
         } else if (kern == KERN_TALL) {
             if (a.a_kmajor && a.b_kmajor) CAPDEC_RING_LAUNCH(true, true, 2, 2, 8, 3, big_tiles);

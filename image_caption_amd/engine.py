@@ -280,39 +280,45 @@ class DecoderEngine:
             h1 = self.buf(f"h1.{i}", (M, d), cdt, dev)
             mean1 = self.buf(f"mean1.{i}", (M,), torch.float32, dev)
             rstd1 = self.buf(f"rstd1.{i}", (M,), torch.float32, dev)
-            ops.ln_fwd(x_in, w["norm1.weight"], w["norm1.bias"], h1, mean1, rstd1)
+            with self._span("block_ln_fwd"):
+                ops.ln_fwd(x_in, w["norm1.weight"], w["norm1.bias"], h1, mean1, rstd1)
         else:
             h1, mean1, rstd1 = h1_ready
         qkv = self.buf(f"qkv.{i}", (M, 3 * d), cdt, dev)
         scale = hd ** -0.5
         # in_proj: the block's own, or the pair with norm1's affine folded in (h1 then holds the normalised rows)
         in_w, in_b = in_proj if in_proj is not None else (w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"])
-        if q_start == 0:
-            ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d)
-        else:
-            ops.gemm(h1, in_w[d:], qkv[:, d:], bias=in_b[d:])
-            ops.gemm(h1[r0:], in_w[:d], qkv[r0:, :d], bias=in_b[:d], col_scale=scale, col_scale_n=d)
+        with self._span("block_qkv_fwd"):
+            if q_start == 0:
+                ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d)
+            else:
+                ops.gemm(h1, in_w[d:], qkv[:, d:], bias=in_b[d:])
+                ops.gemm(h1[r0:], in_w[:d], qkv[r0:, :d], bias=in_b[:d], col_scale=scale, col_scale_n=d)
         attn_o = self.buf(f"attn_o.{i}", (M, d), cdt, dev)
         lse = self.buf(f"lse.{i}", (B * H * S,), torch.float32, dev)
         k_attn = self._keys(4 * i + 0, step, train)
-        ops.attn_fwd_packed(qkv, attn_o, lse, B, H, S, hd, q_start=q_start, nq=S - q_start,
-                            mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn)
+        with self._span("block_attn_fwd"):
+            ops.attn_fwd_packed(qkv, attn_o, lse, B, H, S, hd, q_start=q_start, nq=S - q_start,
+                                mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn)
         x_mid = self.buf(f"x_mid.{i}", (Mt, d), torch.float32, dev)
         k_r1 = self._keys(4 * i + 1, step, train)
-        ops.gemm(attn_o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], drop=k_r1, residual=x_in[r0:])
+        with self._span("block_out_proj_fwd"):
+            ops.gemm(attn_o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], drop=k_r1, residual=x_in[r0:])
         h2 = self.buf(f"h2.{i}", (Mt, d), cdt, dev)
         mean2 = self.buf(f"mean2.{i}", (Mt,), torch.float32, dev)
         rstd2 = self.buf(f"rstd2.{i}", (Mt,), torch.float32, dev)
-        ops.ln_fwd(x_mid, w["norm2.weight"], w["norm2.bias"], h2, mean2, rstd2)
+        with self._span("block_ln_fwd"):
+            ops.ln_fwd(x_mid, w["norm2.weight"], w["norm2.bias"], h2, mean2, rstd2)
         a1 = self.buf(f"a1.{i}", (Mt, ff), cdt, dev)
         k_h = self._keys(4 * i + 2, step, train)
         z1 = None
         if self.opt.activation == "gelu" and train:
             z1 = self.buf(f"z1.{i}", (Mt, ff), cdt, dev)
-        ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation], drop=k_h, aux_out=z1)
         x_out = self.buf(f"x_out.{i}", (Mt, d), torch.float32, dev)
         k_r2 = self._keys(4 * i + 3, step, train)
-        ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid)
+        with self._span("block_mlp_fwd"):
+            ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation], drop=k_h, aux_out=z1)
+            ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid)
         sv.update(x_in=x_in, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x_mid=x_mid, h2=h2,
                   mean2=mean2, rstd2=rstd2, a1=a1, z1=z1, q_start=q_start, keys=(k_attn, k_r1, k_h, k_r2),
                   folded=in_proj is not None)
@@ -372,8 +378,9 @@ class DecoderEngine:
                     # LayerNorm backward that must return an input gradient): otherwise they are not kept, and
                     # the backward reads img / sos / cap again
                     x0 = self.buf("x0", (M, d), torch.float32, dev)
-                    ops.concat_ln_fwd(img, sos, cap, g1, b1, pos=pos, x_out=x0,
-                                      x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
+                    with self._span("join_ln_fwd"):
+                        ops.concat_ln_fwd(img, sos, cap, g1, b1, pos=pos, x_out=x0,
+                                          x_row0=0 if keep_joined else q0 * B, y_out=h1, mean=mean1, rstd=rstd1)
                     concat_src = ("concat", img, sos, cap, pos)
                 else:
                     # a strided seq-first slice (dataset[:, i:j, :]) is normalised where it lies, without a contiguous
@@ -504,33 +511,40 @@ class DecoderEngine:
         G("linear1.bias").zero_()            # summed by atomics in a GEMM epilogue; the other bias gradients are overwritten
         # ---- MLP
         g2 = self.buf("g_res", (Mt, d), cdt, dev)
-        ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
+        with self._span("block_rowops_bwd"):
+            ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
         self._on_side_stream(lambda: ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         gcws = self.buf("gate_colsum_ws", ((Mt + 63) // 64 * ff * 4,), torch.uint8, dev)     # one partial row of bias sums per 64 rows
-        if self.opt.activation == "relu":
-            ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
-                     gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
-        else:
-            ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
-                     gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
+        with self._span("block_mlp_dgrad"):
+            if self.opt.activation == "relu":
+                ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
+                         gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
+            else:
+                ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
+                         gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
         self._on_side_stream(lambda: ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dh2 = self.buf("dh", (Mt, d), cdt, dev)
-        ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
+        with self._span("block_mlp_dgrad"):
+            ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
         dx_mid = self.buf(f"dx_mid", (Mt, d), torch.float32, dev)
         lnws = self.buf("ln_ws", (ops.ln_bwd_workspace(M, d),), torch.uint8, dev)
-        ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
+        with self._span("block_ln_bwd"):
+            ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
         # ---- attention
         g1 = self.buf("g_res1", (Mt, d), cdt, dev)        # not g2's buffer: a side-stream product may still read that
-        ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"), csws)
+        with self._span("block_rowops_bwd"):
+            ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"), csws)
         self._on_side_stream(lambda: ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True,
                                               b_kmajor=True, workspace=skws))
         dattn = self.buf("dattn", (M, d), cdt, dev)
-        ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
+        with self._span("block_out_proj_dgrad"):
+            ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
         dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
         delta = self.buf("delta", (B * H * S,), torch.float32, dev)
-        ops.attn_bwd_packed(sv["qkv"], sv["attn_o"], sv["lse"], dattn, dqkv, delta, B, H, S, hd, q_start=q_start, nq=S - q_start,
-                            mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5)
+        with self._span("block_attn_bwd"):
+            ops.attn_bwd_packed(sv["qkv"], sv["attn_o"], sv["lse"], dattn, dqkv, delta, B, H, S, hd, q_start=q_start, nq=S - q_start,
+                                mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5)
         gin_w, gin_b = G("self_attn.in_proj_weight"), G("self_attn.in_proj_bias")
         h1 = sv["h1"]
         if q_start == 0:
@@ -577,18 +591,20 @@ class DecoderEngine:
             self._join_side_stream()
             return None
         dh1 = self.buf("dh1", (M, d), torch.float32, dev)
-        if q_start == 0:
-            ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
-        else:
-            ops.gemm(dqkv[:, d:], in_w[d:], dh1, M=M, N=d, K=2 * d, b_kmajor=True)
-            ops.gemm(dqkv[r0:, :d], in_w[:d], dh1[r0:], M=Mt, N=d, K=d, b_kmajor=True, accumulate=True)
+        with self._span("block_qkv_dgrad"):
+            if q_start == 0:
+                ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
+            else:
+                ops.gemm(dqkv[:, d:], in_w[d:], dh1, M=M, N=d, K=2 * d, b_kmajor=True)
+                ops.gemm(dqkv[r0:, :d], in_w[:d], dh1[r0:], M=Mt, N=d, K=d, b_kmajor=True, accumulate=True)
         if q_start == 0:
             dres = dx_mid
         else:
             dres = self.buf("dres", (M, d), torch.float32, dev, zero=True)
             dres[r0:].copy_(dx_mid)
         dx_in = self.buf(f"dx_in.{i % 2}", (M, d), torch.float32, dev)
-        ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
+        with self._span("block_ln_bwd"):
+            ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
         self._join_side_stream()
         return dx_in
 
