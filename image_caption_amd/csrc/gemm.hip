@@ -17,6 +17,7 @@
 // wave-private LDS tile, row-major, so global stores are 16 B per lane and contiguous
 // across 8-16 lanes.
 #include "common.h"
+#include "head_fwd.h"
 
 namespace {
 
@@ -1431,13 +1432,33 @@ __device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2
     }
 }
 constexpr int FIN_ROWS = 32, FIN_GROUPS = 32;
+// dot = NULL: the label's logit comes from zlabel[] (written by the forward epilogue).  Otherwise it is formed here,
+// z[m, label] = h[m, :] . W[label, :] + bias[label] (bf16 operands, f32 sum in a fixed order): thread (row, group)
+// takes every 32nd 16-byte chunk of the two rows.
+struct LabelDot { const bf16_t* h; const bf16_t* W; const float* bias; long ldh, ldw; int d; };
 __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, const float* zlabel, const int64_t* labels,
                                                            int ce_B, int ce_L, long M, int np,
                                                            float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
-                                                           float* rowloss, int32_t* rowcorrect) {
+                                                           float* rowloss, int32_t* rowcorrect, LabelDot dot) {
     __shared__ RowFold sh[FIN_GROUPS][FIN_ROWS];
+    __shared__ float zdot[FIN_GROUPS][FIN_ROWS + 1];
     const int r = threadIdx.x & (FIN_ROWS - 1), w = threadIdx.x / FIN_ROWS;
     const long m = (long)blockIdx.x * FIN_ROWS + r;
+    if (dot.h && labels) {
+        // lanes of a wave: 32 rows x 2 groups; a row's 32 groups read 32 consecutive chunks
+        float a = 0.f;
+        if (m < M) {
+            const long l = m / ce_B, b = m - l * ce_B;
+            const bf16_t* hr = dot.h + m * dot.ldh;
+            const bf16_t* wr = dot.W + labels[b * ce_L + l] * dot.ldw;
+            for (int c = w * 8; c < dot.d; c += FIN_GROUPS * 8) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(hr + c), y = *reinterpret_cast<const bf16x8*>(wr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fmaf((float)x[e], (float)y[e], a);
+            }
+        }
+        zdot[w][r] = a;
+    }
     RowFold t = {-INFINITY, 0x7fffffff, -INFINITY, 0.f};
     if (m < M) {
         for (int sl = w; sl < np; sl += FIN_GROUPS) {
@@ -1460,8 +1481,17 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
         if (margin_out) margin_out[m] = t.m1 - t.m2;
         if (labels) {
             const long l = m / ce_B, b = m - l * ce_B;
-            rowloss[m] = lse - zlabel[m];
-            rowcorrect[m] = ((long)t.a1 == labels[b * ce_L + l]) ? 1 : 0;
+            const long lab = labels[b * ce_L + l];
+            float zl;
+            if (dot.h) {
+                zl = dot.bias ? dot.bias[lab] : 0.f;
+#pragma unroll 1
+                for (int i = 0; i < FIN_GROUPS; ++i) zl += zdot[i][r];
+            } else {
+                zl = zlabel[m];
+            }
+            rowloss[m] = lse - zl;
+            rowcorrect[m] = ((long)t.a1 == lab) ? 1 : 0;
         }
     }
 }
@@ -1801,7 +1831,25 @@ void fill_head_args(GemmArgs& a, const void* h, const void* W, const float* bias
     a.A = h; a.B = W; a.M = (int)M; a.N = V; a.K = d; a.lda = ldh; a.ldb = ldw;
     a.bias = bias;
 }
+// Which geometry of the persistent forward kernel (head_fwd.hip) runs this forward, -1: the generic tile kernel.
+// bf16 products large enough to occupy every CU for several tiles take it; diagnostic modes 8 / 9 force its two
+// geometries at any size, any other non-zero mode forces the generic kernels.
+int g_head_fwd_geometry = 1;
+int head_fwd_choice(const GemmArgs& a, int dtype, HeadFwdArgs& ha) {
+    if (dtype != CAPDEC_BF16 || a.want_sec) return -1;
+    ha = HeadFwdArgs{(const bf16_t*)a.A, (const bf16_t*)a.B, a.bias, (bf16_t*)a.C, a.lda, a.ldb, a.ldc, a.M, a.N, a.K,
+                     a.store_cols, a.part4, a.np, g_stamps};
+    if (a.C && a.out_dtype != CAPDEC_BF16) return -1;
+    if (!head_fwd_supported(ha)) return -1;
+    if (g_gemm_mode == 8) return 0;
+    if (g_gemm_mode == 9) return 1;
+    if (g_gemm_mode != 0) return -1;
+    return (long)a.M * a.N >= (1L << 24) ? g_head_fwd_geometry : -1;
+}
 }  // namespace
+
+// diagnostic hook (not part of the declared ABI): default geometry of the persistent forward kernel
+extern "C" void capdecdbg_head_fwd_geometry(int g) { g_head_fwd_geometry = g < 0 ? -1 : (g ? 1 : 0); }     // -1: never
 
 extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
                                     long M, int V, int d, long ldh, long ldw,
@@ -1825,11 +1873,20 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     a.labels = labels; a.ce_B = B; a.ce_L = L;
     a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
+    LabelDot dot = {};
+    HeadFwdArgs ha;
+    const int geo = head_fwd_choice(a, dtype, ha);
+    int rc;
+    if (geo >= 0) {
+        rc = head_fwd_launch(ha, geo, st);
+        dot = LabelDot{(const bf16_t*)h, (const bf16_t*)W, bias, ldh, ldw, d};     // that kernel leaves the label's logit to the finalize pass
+    } else {
+        rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, labels, B, L, M, ws.np,
-                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect);
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, dot);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -1852,11 +1909,13 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     a.ce_B = 1; a.ce_L = 1;
     a.part4 = ws.part4; a.zlabel = ws.zlabel; a.np = ws.np; a.want_sec = margin != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
+    HeadFwdArgs ha;
+    const int geo = margin ? -1 : head_fwd_choice(a, dtype, ha);      // the second maximum (margins) is the generic epilogue's
+    const int rc = geo >= 0 ? head_fwd_launch(ha, geo, st) : launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
-                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr);
+                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr, LabelDot{});
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -739,7 +739,8 @@ class DecoderEngine:
         dd.blocks = blocks
         dd.head_w, dd.head_b, dd.ld_head_w = W.head_w.data_ptr(), W.head_b.data_ptr(), W.head_w.stride(0)
         dd.emb, dd.pos = emb.data_ptr(), (pos.data_ptr() if pos is not None else None)
-        dd.x_last, dd.ids, dd.done, dd.out, dd.margin = xl.data_ptr(), ids.data_ptr(), done.data_ptr(), out.data_ptr(), mg.data_ptr()
+        dd.x_last, dd.ids, dd.done, dd.out = xl.data_ptr(), ids.data_ptr(), done.data_ptr(), out.data_ptr()
+        dd.margin = mg.data_ptr() if return_margins else None       # unasked for, the head runs without the second maximum
         dd.max_len, dd.eos_id, dd.pad_id = max_len, eos_id, pad_id
         dd.workspace, dd.workspace_bytes = ws.data_ptr(), wsb
         stream = _lib.stream_ptr()
@@ -775,7 +776,7 @@ class DecoderEngine:
         for t in range(max_len):
             ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
             with self._span("logits_argmax"):
-                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg, ws)
+                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg if return_margins else None, ws)
             if return_margins:
                 margins[:, t].copy_(mg)
             ops.greedy_update(ids, done, out, t, eos_id, pad_id)

@@ -128,6 +128,84 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     close(dbias, ref_dl.sum(0), 1e-2, "dbias")
 
 
+@pytest.mark.parametrize("mode", [8, 9])              # the two tile geometries of the persistent forward kernel
+@pytest.mark.parametrize("B_,L,V,d,with_bias", [
+    (5, 8, 1111, 256, True),            # one ragged tile in M, ragged in N
+    (37, 9, 2000, 288, False),          # 333 rows: two M-tiles, the second ragged; no bias; 9 k-steps
+    (1, 3, 130, 256, True),             # fewer rows than one MFMA block, fewer columns than one tile
+    (64, 9, 50260, 768, True),          # more tiles than workgroups: every workgroup walks several
+])
+def test_persistent_logits_ce_forward(gemm_mode, mode, B_, L, V, d, with_bias):
+    """The persistent bf16 forward (packed max/argmax, numerators stored from registers, the label's logit formed by
+    the finalize pass) against torch, with and without kept numerators, and as the argmax entry point."""
+    M = B_ * L
+    h = rnd(M, d, dtype=torch.bfloat16, seed=71)
+    w = rnd(V, d, dtype=torch.bfloat16, scale=2.0 / math.sqrt(d), seed=72)
+    b = rnd(V, seed=73) if with_bias else None
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(74)).to(DEV)
+    labels[0, 0], labels[-1, -1] = V - 1, 0
+    z = h.float() @ w.float().t() + (b if with_bias else 0.0)
+    lab_rows = labels.t().reshape(-1)
+    ref_lse = torch.logsumexp(z, 1)
+    ref_loss = (ref_lse - z.gather(1, lab_rows[:, None])[:, 0]).sum()
+    ref_dl = (torch.softmax(z, 1) - torch.nn.functional.one_hot(lab_rows, V)) / M
+    top2 = z.topk(2, -1)
+    decided = (top2.values[:, 0] - top2.values[:, 1]) > 0.05
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    bws = torch.empty(ops.logits_ce_bwd_workspace(M, V), dtype=torch.uint8, device=DEV)
+    for keep in (True, False):
+        lse, amax = torch.full((M,), float("nan"), device=DEV), torch.full((M,), -1, dtype=torch.int32, device=DEV)
+        ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+        dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=torch.bfloat16) if keep else None
+        gemm_mode(mode)
+        ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, probs=dl)
+        gemm_mode(0)
+        close(lse, ref_lse, 2e-3, "lse")
+        assert abs(ls.item() - ref_loss.item()) <= 2e-3 * abs(ref_loss.item())
+        assert torch.equal(amax[decided].long(), top2.indices[decided, 0])
+        assert int(amax.min()) >= 0 and int(amax.max()) < V
+        if keep:
+            assert float(dl.float().min()) >= 0.0 and float(dl.float().max()) <= 1.0 + 1e-5     # also: no NaN left
+            assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+            dbias = torch.full((V,), float("nan"), device=DEV)
+            ops.logits_ce_bwd_from_probs(dl, V, labels, B_, L, lse, 1.0 / M, ws, dbias, bws)
+            close(dl[:, :V], ref_dl, 1e-2, "dl from kept numerators")
+            close(dbias, ref_dl.sum(0), 1e-2, "dbias")
+    ids = torch.full((M,), -1, dtype=torch.int64, device=DEV)
+    gemm_mode(mode)
+    ops.logits_argmax(h, w, b, ids, None, ws)
+    gemm_mode(0)
+    assert torch.equal(ids[decided], top2.indices[decided, 0])
+    assert int(ids.min()) >= 0 and int(ids.max()) < V
+
+
+def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
+    """200 launches of each geometry on one input give bit-identical numerators and partial sums: the operand ring's
+    waits are sufficient on every tile of every launch (a stage read before it had landed shows up here)."""
+    B_, L, V, d = 64, 32, 50260, 768
+    M = B_ * L
+    h = rnd(M, d, dtype=torch.bfloat16, seed=81)
+    w = rnd(V, d, dtype=torch.bfloat16, scale=0.05, seed=82)
+    b = rnd(V, seed=83)
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(84)).to(DEV)
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    lse, amax = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    dl = torch.empty(M, Vp, device=DEV, dtype=torch.bfloat16)
+    for mode in (8, 9):
+        gemm_mode(mode)
+        ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, probs=dl)
+        first = (dl.clone(), lse.clone(), amax.clone())
+        bad = torch.zeros((), dtype=torch.int64, device=DEV)
+        for _ in range(200):
+            ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, probs=dl)
+            bad += (dl.view(torch.int16) != first[0].view(torch.int16)).sum() + (lse != first[1]).sum() + (amax != first[2]).sum()
+        gemm_mode(0)
+        assert int(bad) == 0, f"mode {mode}: {int(bad)} elements differed between launches"
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 2e-5)])
 @pytest.mark.parametrize("B_,L,V,d", [(5, 8, 1111, 64), (16, 32, 50260, 768), (3, 8, 503, 64)])
 def test_logits_ce_backward_from_kept_numerators(dtype, tol, B_, L, V, d):

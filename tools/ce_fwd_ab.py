@@ -46,8 +46,10 @@ def main():
     big = torch.empty(1 << 28, device=DEV)          # 1 GiB written between launches: every launch starts from cold caches
 
     def run(keep, cold):
-        if cold:
+        if cold == 1:
             big.fill_(1.0)
+        elif cold == 2:                             # caches turned over by reads: nothing dirty left behind
+            torch.sum(big[: 1 << 27], dtype=torch.float32)
         ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws, probs=probs if keep else None)
 
     ref = {}
@@ -66,18 +68,24 @@ def main():
     lib.capdecdbg_gemm_mode(0)
     tfill = timeit(lambda: big.fill_(1.0), 5)
     fl = 2.0 * Mt * V * d
-    print("mode | no numerators: warm us (TFLOP/s) | numerators: warm us (TFLOP/s) | numerators, cold caches us")
-    res = {m: [[], [], []] for m in modes}
+    tsum = timeit(lambda: torch.sum(big[: 1 << 27], dtype=torch.float32), 5)
+    print("mode | no numerators: warm us (TFLOP/s) | numerators: warm us (TFLOP/s) | numerators, cold caches us | "
+          "no numerators, cold | numerators, caches turned over by reads | no numerators, same")
+    res = {m: [[], [], [], [], [], []] for m in modes}
     for _ in range(5):
         for m in modes:
             lib.capdecdbg_gemm_mode(m)
             res[m][0].append(timeit(lambda: run(False, False)))
             res[m][1].append(timeit(lambda: run(True, False)))
-            res[m][2].append(timeit(lambda: run(True, True), 5) - tfill)
+            res[m][2].append(timeit(lambda: run(True, 1), 5) - tfill)
+            res[m][3].append(timeit(lambda: run(False, 1), 5) - tfill)
+            res[m][4].append(timeit(lambda: run(True, 2), 5) - tsum)
+            res[m][5].append(timeit(lambda: run(False, 2), 5) - tsum)
     lib.capdecdbg_gemm_mode(0)
     for m in modes:
-        a, b, c = (sorted(v)[2] for v in res[m])
-        print(f"{m:4d} | {a * 1e3:8.1f} ({fl / a / 1e9:6.1f}) | {b * 1e3:8.1f} ({fl / b / 1e9:6.1f}) | {c * 1e3:8.1f} ({fl / c / 1e9:6.1f})")
+        a, b, c, d2, e2, f2 = (sorted(v)[2] for v in res[m])
+        print(f"{m:4d} | {a * 1e3:8.1f} ({fl / a / 1e9:6.1f}) | {b * 1e3:8.1f} ({fl / b / 1e9:6.1f}) | {c * 1e3:8.1f} ({fl / c / 1e9:6.1f})"
+              f" | {d2 * 1e3:8.1f} | {e2 * 1e3:8.1f} | {f2 * 1e3:8.1f}")
 
 
 if __name__ == "__main__":

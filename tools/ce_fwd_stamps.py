@@ -32,8 +32,33 @@ def main():
     ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
     probs = torch.empty(Mt, (V + 127) // 128 * 128, device=DEV, dtype=torch.bfloat16)
     nt = (Mt // 128) * ((V + 127) // 128)
+    lib.capdecdbg_gemm_stamps.argtypes = [ctypes.c_void_p]
+
+    def persistent(m, keep):
+        """The persistent kernel (modes 8 / 9) stamps per WORKGROUP: start, cycles summed over its tiles' k-loops and
+        epilogues, end."""
+        st = torch.zeros(512 * 8, dtype=torch.int64, device=DEV)
+        fn = lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws, probs=probs if keep else None)  # noqa: E731
+        fn(); fn()
+        torch.cuda.synchronize()
+        lib.capdecdbg_gemm_stamps(st.data_ptr())
+        fn()
+        torch.cuda.synchronize()
+        lib.capdecdbg_gemm_stamps(None)
+        s = st.view(512, 8).double().cpu()
+        s = s[s[:, 7] > 0]
+        tot = s[:, 7] - s[:, 0]
+        tiles = (Mt // 256) * ((V + (127 if m == 8 else 255)) // (128 if m == 8 else 256)) / s.shape[0]
+        print(f"mode {m}{' keeping numerators' if keep else ''}: {s.shape[0]} workgroups, {tiles:.1f} tiles each; per workgroup: total {tot.median():.0f} "
+              f"(min {tot.min():.0f}, max {tot.max():.0f}), k-loops {s[:, 1].median():.0f} ({s[:, 1].median() / tiles / (d // 32):.0f} per step), "
+              f"epilogues {s[:, 2].median():.0f} ({s[:, 2].median() / tiles:.0f} per tile); span {s[:, 7].max() - s[:, 0].min():.0f} cycles")
+
     for m in modes:
         lib.capdecdbg_gemm_mode(m)
+        if m in (8, 9):
+            persistent(m, False)
+            persistent(m, True)
+            continue
         gemm_stamps.stamp_call(f"mode {m}: logits+CE fwd", lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws), nt, d // 32)
         gemm_stamps.stamp_call(f"mode {m}: logits+CE fwd keeping numerators",
                                lambda: ops.logits_ce_fwd(x, w, bias, labels, B, L, lse, amax, ls, cr, ws, probs=probs), nt, d // 32)
