@@ -1188,7 +1188,19 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
         step(fb[1], fb[0], fa7, fa[7]);
     }
     if (kt < nk) step(fb[0], fb[1], fa[7], fa7);
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // the fragment reads of the stage past the end are in (their registers are reused)
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // the fragment reads of the stage past the end are in
+    // Those last reads feed nothing, and to the compiler an inline-assembly read is complete when issued: without the
+    // uses below it hands their destination registers to the next value at once -- in the last step that was the
+    // 64-bit constant the refill descriptors' byte count is clamped against, which the landing LDS data then
+    // overwrote: an unbounded descriptor on exactly the refills that reach past the end of the operand.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fa[i])));
+    asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fa7)));
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[0][j])));
+        asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[1][j])));
+    }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last MFMAs (opaque to the compiler) have written back
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // trailing refills and fragment reads are done before LDS is reused
     __syncthreads();
@@ -1332,7 +1344,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_WIDE;
         else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
-        else if (g_gemm_mode == 7 && ring_ok && !any_km) kern = KERN_TALLP;
+        else if (g_gemm_mode == 7 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_TALLP;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
         else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
@@ -1372,8 +1384,16 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(256), PipeGeo<TJ>::LDS, st, a);     \
     } while (0)
 #define CAPDEC_QUAD_LAUNCH(AT, BT) CAPDEC_PIPE_LAUNCH(AT, BT, EPI_STD, 8, wide_tiles)
-        if (kern == KERN_TALLP) CAPDEC_PIPE_LAUNCH(false, false, EPI, 4, big_tiles);
-        else
+        if (kern == KERN_TALLP) {
+            if constexpr (EPI == EPI_STD) {
+                if (a.a_kmajor && a.b_kmajor) CAPDEC_PIPE_LAUNCH(true, true, EPI_STD, 4, big_tiles);
+                else if (a.a_kmajor) CAPDEC_PIPE_LAUNCH(true, false, EPI_STD, 4, big_tiles);
+                else if (a.b_kmajor) CAPDEC_PIPE_LAUNCH(false, true, EPI_STD, 4, big_tiles);
+                else CAPDEC_PIPE_LAUNCH(false, false, EPI_STD, 4, big_tiles);
+            } else {
+                CAPDEC_PIPE_LAUNCH(false, false, EPI, 4, big_tiles);
+            }
+        } else
         if (kern == KERN_QUAD) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);

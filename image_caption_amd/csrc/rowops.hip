@@ -204,20 +204,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
 }
 
 // 64 columns per block; 16 row groups each sum a fixed interleaved subset of the
-// per-block partials, then a fixed-order fold: deterministic for a given grid
-__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta) {
+// per-block partials, then a fixed-order fold: deterministic for a given grid.
+// gridDim.y > 1: block row y folds partial rows [y * chunk, (y + 1) * chunk) into row pair y of `dgamma`
+// (a [gridDim.y][2][d] array, dbeta unused), which a second launch folds to the end.
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta, int chunk) {
     __shared__ float sa[16][64], sb[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
+    int k0 = 0, k1 = nblk;
+    if (gridDim.y > 1) {
+        k0 = blockIdx.y * chunk;
+        k1 = min(nblk, k0 + chunk);
+        dbeta = dgamma + ((long)blockIdx.y * 2 + 1) * d;
+        dgamma = dgamma + ((long)blockIdx.y * 2) * d;
+    }
     float a = 0.f, b = 0.f;
     if (c < d)
-        for (int k = ty; k < nblk; k += 16) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
+        for (int k = k0 + ty; k < k1; k += 16) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
     sa[ty][tx] = a; sb[ty][tx] = b;
     __syncthreads();
     if (ty == 0 && c < d) {
         float ra = 0.f, rb = 0.f;
         for (int j = 0; j < 16; ++j) { ra += sa[j][tx]; rb += sb[j][tx]; }
         dgamma[c] = ra; dbeta[c] = rb;
+    }
+}
+
+// Folds nb partial row pairs into dgamma / dbeta.  Many pairs (the row-streaming backward writes one per workgroup)
+// are folded in two launches, the first spread over LN_FOLD_GROUPS times as many workgroups; `scratch` holds
+// LN_FOLD_GROUPS row pairs.
+constexpr int LN_FOLD_GROUPS = 32;
+void launch_ln_finalize(const float* partial, int nb, int d, float* dgamma, float* dbeta, float* scratch, hipStream_t st) {
+    const unsigned gx = (unsigned)((d + 63) / 64);
+    if (scratch && nb >= 8 * LN_FOLD_GROUPS) {
+        const int chunk = (nb + LN_FOLD_GROUPS - 1) / LN_FOLD_GROUPS;
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx, LN_FOLD_GROUPS), dim3(1024), 0, st, partial, nb, d, scratch, (float*)nullptr, chunk);
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx), dim3(1024), 0, st, (const float*)scratch, LN_FOLD_GROUPS, d, dgamma, dbeta, 0);
+    } else {
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx), dim3(1024), 0, st, partial, nb, d, dgamma, dbeta, 0);
     }
 }
 
@@ -519,7 +543,7 @@ extern "C" int capdec_ln_fwd(const float* x, const float* gamma, const float* be
     return CAPDEC_OK;
 }
 
-extern "C" long capdec_ln_bwd_workspace(long M, int d) { return (long)ln_bwd_blocks(M, true) * 2 * d * 4; }
+extern "C" long capdec_ln_bwd_workspace(long M, int d) { return (long)(ln_bwd_blocks(M, true) + LN_FOLD_GROUPS) * 2 * d * 4; }
 
 extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                              const float* mean, const float* rstd, long M, int d,
@@ -537,7 +561,8 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
     if (dy_dtype == CAPDEC_BF16) { if (d <= 1024) CAPDEC_LNB_PLAIN(bf16_t, 4); else CAPDEC_LNB_PLAIN(bf16_t, 8); }
     else { if (d <= 1024) CAPDEC_LNB_PLAIN(float, 4); else CAPDEC_LNB_PLAIN(float, 8); }
 #undef CAPDEC_LNB_PLAIN
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
+    // the workspace (capdec_ln_bwd_workspace) holds the fold's scratch behind the largest grid's partials
+    launch_ln_finalize((const float*)partial, nb, d, dgamma, dbeta, (float*)partial + (long)ln_bwd_blocks(M, true) * 2 * d, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -564,7 +589,7 @@ int ln_bwd_affine_from_sources(const void* dy, int dy_dtype, const void* img, lo
     else CAPDEC_LNB(float, float);
 #undef CAPDEC_LNB
 #undef CAPDEC_LNB2
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, d, dgamma, dbeta);
+    launch_ln_finalize((const float*)partial, nb, d, dgamma, dbeta, nullptr, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -771,7 +796,7 @@ extern "C" int capdec_ln_fold_bwd(float* G, long ldg, const float* s, const void
         hipLaunchKernelGGL(ln_fold_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, G, ldg, s, (const bf16_t*)W, ldw, gamma, beta, N, K, (float*)partial);
     else
         hipLaunchKernelGGL(ln_fold_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, G, ldg, s, (const float*)W, ldw, gamma, beta, N, K, (float*)partial);
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, (const float*)partial, nb, K, dgamma, dbeta);
+    launch_ln_finalize((const float*)partial, nb, K, dgamma, dbeta, nullptr, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -119,11 +119,21 @@ class BatchSource:
             self._copy_stream = torch.cuda.Stream(device=self.device)
 
     @staticmethod
-    def _pin(x: torch.Tensor) -> torch.Tensor:
+    def _pin(x: torch.Tensor, host_fraction: float = 0.5) -> torch.Tensor:
+        """A pinned copy of the split when it fits comfortably in the host memory available now (pinning materialises
+        the whole slice); otherwise the view itself -- a mapped file larger than memory streams through pageable copies."""
+        nbytes = x.numel() * x.element_size()
+        try:
+            import psutil
+            available = psutil.virtual_memory().available
+        except Exception:
+            available = 0
+        if nbytes > host_fraction * available:
+            return x
         try:
             return x.contiguous().pin_memory()
         except RuntimeError:
-            return x                                 # a mapped file larger than pinnable memory: pageable copies still work
+            return x
 
     def __len__(self) -> int:
         n = self.hi - self.lo

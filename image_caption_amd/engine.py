@@ -547,17 +547,20 @@ class DecoderEngine:
                                 mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5)
         gin_w, gin_b = G("self_attn.in_proj_weight"), G("self_attn.in_proj_bias")
         h1 = sv["h1"]
+        # in_proj's bias gradient (column sums of dQKV, a pure read stream) goes with its weight gradient: nothing
+        # downstream waits for it, and next to the dgrad product on the main stream it costs next to nothing
+        csws_side = self.buf("colsum_ws_side", (csws.numel(),), torch.uint8, dev)
         if q_start == 0:
-            ops.colsum(dqkv, gin_b, csws)
-            self._on_side_stream(lambda: ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
+            def in_proj_grads():
+                ops.colsum(dqkv, gin_b, csws_side)
+                ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
         else:
-            ops.colsum(dqkv[r0:, :d], gin_b[:d], csws)
-            ops.colsum(dqkv[:, d:], gin_b[d:], csws)
-
-            def in_proj_wgrads():
+            def in_proj_grads():
+                ops.colsum(dqkv[r0:, :d], gin_b[:d], csws_side)
+                ops.colsum(dqkv[:, d:], gin_b[d:], csws_side)
                 ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
                 ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
-            self._on_side_stream(in_proj_wgrads)
+        self._on_side_stream(in_proj_grads)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
         if sv.get("folded"):

@@ -103,3 +103,14 @@ def test_captions_from_ids_cuts_at_eos_and_drops_specials():
             return " ".join(f"w{i}" for i in t)
     assert captions_from_ids(ids, Tok(), vocab_size=V) == ["w11 w12", "w5 w6 w7 w8 w9 w10", ""]
     assert captions_from_ids([[1, 2, 9, 3]], eos_id=9, pad_id=0, sos_id=7) == [[1, 2]]
+
+
+def test_batch_source_pins_only_what_fits_in_host_memory():
+    """A split larger than the allowed share of the available host memory stays the (possibly memory-mapped) view it
+    is: pinning would first materialise the whole slice."""
+    import torch
+    from image_caption_amd.dataset import BatchSource
+    x = torch.zeros(4, 10, 8)[:, 2:7, :]
+    assert BatchSource._pin(x, host_fraction=0.0) is x
+    y = BatchSource._pin(x, host_fraction=0.5)
+    assert y.shape == x.shape and torch.equal(y, x)

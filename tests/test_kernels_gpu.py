@@ -62,7 +62,7 @@ def gemm_mode():
 
 # 1 register-staged, 2 ring 128x128, 3 ring 256x128 (8 waves), 4 ring 256x128 (4 waves of 128x64),
 # 5 ring 256x256 (8 waves of 128x64; plain products only), 6 pipelined 256x256 with 4 waves of 128x128 (plain products
-# only), 7 pipelined 256x128 with 4 waves of 128x64 (row-major operands)
+# only), 7 pipelined 256x128 with 4 waves of 128x64 (plain products in any layout, row-major with every epilogue)
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 264, 192), (1000, 72, 96), (515, 640, 768), (64, 136, 64)])
 def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
@@ -79,7 +79,7 @@ def test_gemm_every_geometry(gemm_mode, mode, M, N, K):
     close(out2, ref + res, 1.5e-2, f"mode {mode} + residual")
 
 
-@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7])
 @pytest.mark.parametrize("akm,bkm", [(False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(264, 136, 96), (520, 72, 2080), (136, 264, 100)])
 def test_gemm_reduction_major_every_geometry(gemm_mode, mode, akm, bkm, M, N, K):
@@ -241,7 +241,7 @@ def test_logits_ce_backward_from_kept_numerators(dtype, tol, B_, L, V, d):
 
 
 @pytest.mark.parametrize("M,N,K,out", [(768, 256, 4096, torch.float32), (200, 328, 8200, torch.bfloat16), (128, 128, 2048, torch.float32)])
-@pytest.mark.parametrize("mode", [0, 1, 5, 6])
+@pytest.mark.parametrize("mode", [0, 1, 5, 6, 7])
 def test_gemm_split_k(gemm_mode, mode, M, N, K, out):
     gemm_mode(mode)
     # weight-gradient shape: few output tiles, deep K; both operands reduction-major
@@ -259,6 +259,26 @@ def test_gemm_split_k(gemm_mode, mode, M, N, K, out):
         acc = ref.clone()
         ops.gemm(A, B, acc, a_kmajor=True, b_kmajor=True, workspace=ws, accumulate=True)
         close(acc, 2 * ref, 2e-3, "split-k accumulate")
+
+
+@pytest.mark.parametrize("mode", [0, 4, 6, 7])
+def test_head_dgrad_shape_split_k(gemm_mode, mode):
+    """The data gradient of the vocabulary projection as the engine launches it: 8192 x 768 over a reduction of 50304
+    (the padded vocabulary), W reduction-major, split into 8 slabs.  The refills of every workgroup's last steps reach
+    past the end of both operands and rely on their buffer descriptors' byte counts."""
+    M, N, K = 8192, 768, 50304
+    A = rnd(M, K, dtype=torch.bfloat16, scale=0.05, seed=91)
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.05, seed=92)
+    ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device=DEV)
+    ref = A.float() @ B.float()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    gemm_mode(mode)
+    ops.gemm(A, B, out, M=M, N=N, K=K, b_kmajor=True, workspace=ws)
+    base = out.clone()
+    ops.gemm(A, B, out, M=M, N=N, K=K, b_kmajor=True, accumulate=True, workspace=ws)
+    gemm_mode(0)
+    close(base, ref, 1.5e-2, f"mode {mode}")
+    close(out, 2 * ref, 1.5e-2, f"mode {mode}, accumulated")
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float32, 3e-5)])
