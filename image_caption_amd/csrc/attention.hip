@@ -99,6 +99,54 @@ __device__ __forceinline__ void rows_to_lds2(char* lds0, const bf16_t* base0, lo
     }
 }
 
+// The same two matrices held in registers between their fetch and their LDS image: the whole-sequence kernels are
+// persistent, and fetch the next (sequence, head)'s operands while they compute on the current one's -- with one
+// workgroup per CU (both operands of a 300-row sequence fill most of the LDS) nothing else would cover that fetch.
+// A thread owns one 16-byte chunk position of the rows r, r + RP, r + 2 RP, ... (RP = rows that 512 threads cover at
+// once), so its NU loads and stores differ by constant offsets: no address register per load.  Rows from NU * RP on
+// (longer sequences) are fetched when they are stored.
+template <int HD, int NU>
+struct HeadPair {
+    static constexpr int CPR = Geo<HD>::CPR, ROWB = Geo<HD>::ROWB;
+    static constexpr int RP = 512 / CPR;
+    u32x4 a[NU], b[NU];
+    __device__ __forceinline__ void fetch(const bf16_t* base0, long ss0, const bf16_t* base1, long ss1, int row0, int nvalid, int tid) {
+        const int r = tid / CPR, ch = tid - r * CPR;
+        const bf16_t* p0 = base0 + (long)(row0 + r) * ss0 + ch * 8;
+        const bf16_t* p1 = base1 + (long)(row0 + r) * ss1 + ch * 8;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            a[u] = b[u] = u32x4{0, 0, 0, 0};
+            if (r < RP && r + u * RP < nvalid) {
+                a[u] = *reinterpret_cast<const u32x4*>(p0 + (long)(u * RP) * ss0);
+                b[u] = *reinterpret_cast<const u32x4*>(p1 + (long)(u * RP) * ss1);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* lds0, const bf16_t* base0, long ss0, char* lds1, const bf16_t* base1, long ss1,
+                                          int row0, int nvalid, int npad, int tid, int nthreads) {
+        const int r = tid / CPR, ch = tid - r * CPR;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (r < RP && r + u * RP < npad) {
+                *reinterpret_cast<u32x4*>(lds0 + (r + u * RP) * ROWB + ch * 16) = a[u];
+                *reinterpret_cast<u32x4*>(lds1 + (r + u * RP) * ROWB + ch * 16) = b[u];
+            }
+        }
+        for (int c = NU * RP * CPR + tid; c < npad * CPR; c += nthreads) {       // rows past the prefetched ones
+            const int row = c / CPR, cc = c - row * CPR;
+            u32x4 x = u32x4{0, 0, 0, 0}, y = u32x4{0, 0, 0, 0};
+            if (row < nvalid) {
+                x = *reinterpret_cast<const u32x4*>(base0 + (long)(row0 + row) * ss0 + cc * 8);
+                y = *reinterpret_cast<const u32x4*>(base1 + (long)(row0 + row) * ss1 + cc * 8);
+            }
+            *reinterpret_cast<u32x4*>(lds0 + row * ROWB + cc * 16) = x;
+            *reinterpret_cast<u32x4*>(lds1 + row * ROWB + cc * 16) = y;
+        }
+    }
+};
+constexpr int SEQ_NU = 8;      // at 96 columns: 8 x 42 = 336 rows per matrix
+
 // the 4 x KS row-major fragments of a 64-row block of a [S, HD] matrix, straight from global memory:
 // lane (g,i) of tile t gets M[row0 + 16t + i][32ks + 8g .. +7] (zero past S)
 template <int HD>
@@ -142,8 +190,42 @@ __device__ __forceinline__ bf16x8 zero_frag() {
     for (int e = 0; e < 8; ++e) r[e] = (bf16_t)0.f;
     return r;
 }
-__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// v combined with the values the lanes 16, 32 and 48 further on (mod 64) hold.  The whole-sequence forward, whose
+// waves are bound by their own instruction stream, takes the register-swap form (no LDS round trip); the slab
+// kernels and the backward, which wait on memory, keep the shuffles they were measured with (no gain from the swaps).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32pair;
+template <bool SWAP>
+__device__ __forceinline__ float quad_max(float v) {
+    if constexpr (SWAP) {
+        u32pair r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else {
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        return fmaxf(v, __shfl_xor(v, 32, 64));
+    }
+}
+template <bool SWAP>
+__device__ __forceinline__ float quad_sum(float v) {
+    if constexpr (SWAP) {
+        u32pair r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        v += __shfl_xor(v, 16, 64);
+        return v + __shfl_xor(v, 32, 64);
+    }
+}
+
+// two floats -> one dword of two bf16 (a single v_cvt_pk_bf16_f32; element-wise conversions cost two and a permute)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair;
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16pair t;
+    t[0] = (bf16_t)lo; t[1] = (bf16_t)hi;
+    return __builtin_bit_cast(uint32_t, t);
+}
 
 // the value quad lane R holds, in all four lanes of every aligned quad
 template <int R>
@@ -161,21 +243,35 @@ __device__ __forceinline__ int key_limit(int q, int S, int mask_mode, int open_c
 // staged in LDS once and every wave walks the query tiles wave, wave + 8, ...  K, V, Q and O then cross the
 // memory system once per head instead of once per 64-query slab (V) and once per wave (K).
 template <int HD, bool SEQ>
-__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(AttnArgs p) {
+__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
     const int nthreads = blockDim.x;
     char* Vl = smem;
     char* Kl = smem + SP * G::ROWB;                                   // SEQ only
+    const int nheads = p.B * p.H;
+    HeadPair<HD, SEQ ? SEQ_NU : 1> pre;
+    auto fetch_head = [&](int hh) {
+        const int fb = hh / p.H, fh = hh - fb * p.H;
+        pre.fetch((const bf16_t*)p.v + fb * p.v_bs + fh * p.v_hs, p.v_ss, (const bf16_t*)p.k + fb * p.k_bs + fh * p.k_hs, p.k_ss, 0, p.S, tid);
+    };
+    if constexpr (SEQ) fetch_head(blockIdx.x);
+    // SEQ: persistent, the workgroup walks (sequence, head) pairs blockIdx.x, + gridDim.x, ...
+    for (int bh = blockIdx.x;; bh += gridDim.x) {
+    const int b = bh / p.H, h = bh - b * p.H;
     const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
     bf16x8 kf[4][G::KS];
     if constexpr (!SEQ) frags_from_global<HD>(kbase, p.k_ss, 0, p.S, lane, kf);       // first key block, in flight during the staging of V
-    if constexpr (SEQ) rows_to_lds2<HD, 8>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
-    else rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
+    if constexpr (SEQ) {
+        __syncthreads();                                              // every wave is done with the previous head's images
+        pre.store(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
+    } else {
+        rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
+    }
     __syncthreads();
+    bool fetched = !SEQ || bh + (int)gridDim.x >= nheads;            // the next head's operands are on their way (or there is none)
     const int qend = min(p.q_start + p.nq, p.S);
     const int qstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);         // SEQ: the wave's next query tile
     for (int qw = p.q_start + (SEQ ? 0 : blockIdx.y * (nthreads >> 2)) + wave * 16; qw < qend; qw += qstep) {
@@ -193,21 +289,45 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(At
     const int klim = key_limit(q, p.S, p.mask_mode, p.open_cols);           // this lane's query sees keys < klim
     const int klim_wave = key_limit(qw, p.S, p.mask_mode, p.open_cols);     // the smallest limit in the wave (its first query)
 
+    if constexpr (SEQ) {
+        // the query rows are in before the key loop starts: inside it nothing then waits on the memory pipeline, which
+        // the next head's operands enter during this wave's last tile
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, qf[ks])));
+        // SEQ keeps a key block's K fragments in registers too, read from the LDS image one block ahead
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) kf[t][ks] = frag_rows<HD>(Kl, t * 16, ks * 32, lane);
+    }
     for (int kb = 0; kb < SP; kb += 64) {
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                if constexpr (SEQ) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s[t], 0, 0, 0);
-                else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
-            }
+            for (int ks = 0; ks < G::KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+        }
+        // SEQ: V's fragments for the block's first 32 keys are requested now and used after the softmax arithmetic
+        bf16x8 vfr[SEQ ? G::DT : 1];
+        if constexpr (SEQ) {
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) vfr[dt] = frag_cols<HD>(Vl, kb, kb + 16, dt * 16, lane);
         }
         if constexpr (!SEQ) {
             // the next key block's fragments replace the ones just consumed; the softmax and the P V products
             // below cover their latency
             if (kb + 64 < SP) frags_from_global<HD>(kbase, p.k_ss, kb + 64, p.S, lane, kf);
+        } else {
+            if (kb + 64 < SP) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) kf[t][ks] = frag_rows<HD>(Kl, kb + 64 + t * 16, ks * 32, lane);
+            }
+            // the wave's last tile of this head, its query rows consumed: the next head's operands follow them into
+            // the memory pipeline (loads return in order: issued any earlier, the query rows would wait for these)
+            if (!fetched && kb == 0 && qw + qstep >= qend) { fetch_head(bh + gridDim.x); fetched = true; }
         }
         // masking only in key blocks that some query of the wave does not see entirely (a wave-uniform test)
         if (kb + 64 > klim_wave) {
@@ -219,7 +339,7 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(At
         float bm = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
         for (int t = 1; t < 4; ++t) bm = fmaxf(bm, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-        bm = quad_max(bm);
+        bm = quad_max<SEQ>(bm);
         const float m_new = fmaxf(m_run, bm);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * ATT_LOG2E);
@@ -228,27 +348,49 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(At
 #pragma unroll
         for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
         m_run = m_new;
-        bf16x8 pf[2];
+        u32x4 pfu[2];
+        bf16x8 pfe[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             bool keep[4] = {true, true, true, true};
             if (p.drop_thr) dropout_keep4(p.drop_k0, p.drop_k1, idx_row + kb + t * 16 + 4 * g, p.drop_thr, keep);     // the lane's 4 keys: one hash
+            float pk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], ATT_LOG2E, nm2));
                 l_run += pv;
-                // the 1/(1-p) of the dropout is applied once, to the finished row
-                pf[t >> 1][(t & 1) * 4 + r] = (bf16_t)(keep[r] ? pv : 0.f);
+                pk[r] = keep[r] ? pv : 0.f;          // the 1/(1-p) of the dropout is applied once, to the finished row
+            }
+            if constexpr (SEQ) {
+                pfu[t >> 1][(t & 1) * 2 + 0] = pack_bf16(pk[0], pk[1]);
+                pfu[t >> 1][(t & 1) * 2 + 1] = pack_bf16(pk[2], pk[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pfe[t >> 1][(t & 1) * 4 + r] = (bf16_t)pk[r];
             }
         }
+        bf16x8 pf[2];
+        if constexpr (SEQ) { pf[0] = __builtin_bit_cast(bf16x8, pfu[0]); pf[1] = __builtin_bit_cast(bf16x8, pfu[1]); }
+        else { pf[0] = pfe[0]; pf[1] = pfe[1]; }
+        if constexpr (SEQ) {
+            // those of the other 32 keys are requested before the first half's products, which cover their latency
+            bf16x8 vfr2[G::DT];
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int dt = 0; dt < G::DT; ++dt) vfr2[dt] = frag_cols<HD>(Vl, kb + 32, kb + 48, dt * 16, lane);
 #pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    frag_cols<HD>(Vl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
+            for (int dt = 0; dt < G::DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf[0], oacc[dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr2[dt], pf[1], oacc[dt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        frag_cols<HD>(Vl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
+        }
     }
-    const float l = quad_sum(l_run);
+    const float l = quad_sum<SEQ>(l_run);
     const float inv = l > 0.f ? p.drop_scale / l : 0.f;
     if (qok) {
         bf16_t* orow = (bf16_t*)p.o + b * p.o_bs + h * p.o_hs + (long)q * p.o_ss;
@@ -261,6 +403,11 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_fwd_mfma(At
         }
         if (g == 0 && p.lse) p.lse[(long)bh * p.S + q] = m_run + __logf(l);
     }
+    }
+    if constexpr (SEQ) {
+        if (!fetched) fetch_head(bh + gridDim.x);                     // a wave without a query tile
+    }
+    if (!SEQ || bh + (int)gridDim.x >= nheads) break;
     }
 }
 
@@ -304,7 +451,7 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dq_mfma
     const int klim = qok ? key_limit(q, p.S, p.mask_mode, p.open_cols) : 0;
     const int klim_wave = qw + 16 <= qend ? key_limit(qw, p.S, p.mask_mode, p.open_cols) : 0;     // 0: a partial tile always masks
     // delta = rowsum(dO * O): the four lanes (g) of a query hold disjoint quarters of its row
-    const float delta = quad_sum(dsum);
+    const float delta = quad_sum<false>(dsum);
     if (qok && g == 0) p.delta[(long)bh * p.S + q] = delta;       // the key-major kernel reads it
     const uint32_t idx_row = (uint32_t)((bh * p.S + q) * (long)p.S4);
     f32x4 acc[G::DT];
@@ -712,6 +859,9 @@ int fill_args(const capdec_attn_desc* d, AttnArgs& a) {
     return CAPDEC_OK;
 }
 
+// grid of the persistent whole-sequence kernels: one workgroup per CU of the MI355X, each walking (sequence, head) pairs
+unsigned seq_grid(const AttnArgs& a) { const long n = (long)a.B * a.H; return (unsigned)(n < 256 ? n : 256); }
+
 bool strides_ok8(long a, long b, long c) { return (a % 8) == 0 && (b % 8) == 0 && (c % 8) == 0; }
 
 template <typename K>
@@ -748,7 +898,7 @@ extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
         if (a.nq > 64 && 2 * lds <= 160 * 1024) {
             // long query range: one workgroup of 8 waves per (sequence, head), K and V both resident in LDS
             HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, true>, 2 * lds);
-                        hipLaunchKernelGGL((attn_fwd_mfma<HD, true>), dim3(a.B * a.H), dim3(512), 2 * lds, st, a));
+                        hipLaunchKernelGGL((attn_fwd_mfma<HD, true>), dim3(seq_grid(a)), dim3(512), 2 * lds, st, a));
         } else {
             const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;        // a wave per 16 queries, at most 4 per workgroup
             dim3 grid(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), block(64 * nwaves);

@@ -1481,9 +1481,16 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
     }
     RowFold t = {-INFINITY, 0x7fffffff, -INFINITY, 0.f};
     if (m < M) {
-        for (int sl = w; sl < np; sl += FIN_GROUPS) {
-            const f32x4 q = part4[(long)sl * M + m];
-            fold_push(t, q[0], __float_as_int(q[3]), q[2], q[1]);
+        // FIN_UNROLL loads in flight before the first fold: the pass is a latency-bound read of np * 16 bytes per row
+        constexpr int FIN_UNROLL = 6;
+        for (int sl = w; sl < np; sl += FIN_UNROLL * FIN_GROUPS) {
+            f32x4 q[FIN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FIN_UNROLL; ++u)
+                if (sl + u * FIN_GROUPS < np) q[u] = part4[(long)(sl + u * FIN_GROUPS) * M + m];
+#pragma unroll
+            for (int u = 0; u < FIN_UNROLL; ++u)
+                if (sl + u * FIN_GROUPS < np) fold_push(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
         }
     }
     sh[w][r] = t;

@@ -53,6 +53,13 @@ def main():
     add("LayerNorm bwd, affine only, rows from the join sources", M * d * 4 + M * d * 2,
         lambda: ops.concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dg, db, ws))
     add("LayerNorm bwd, affine only, contiguous rows", M * d * 4 + M * d * 2, lambda: ops.ln_bwd(dy, x, gamma, mean, rstd, None, None, dg, db, ws))
+    # with dx: the row stream of a block's backward (dy, x, the residual gradient in, dx out)
+    dx_in, dx_out = r(M, d), torch.empty(M, d, device=DEV)
+    add("LayerNorm bwd with dx, 8192 rows, bf16 dy", Mt * d * (2 + 12), lambda: ops.ln_bwd(dy[:Mt], x[:Mt], gamma, mean[:Mt], rstd[:Mt], dx_in[:Mt], dx_out[:Mt], dg, db, ws))
+    add("LayerNorm bwd with dx, 58624 rows, bf16 dy", M * d * (2 + 12), lambda: ops.ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx_out, dg, db, ws))
+    dyf = r(M, d)
+    add("LayerNorm bwd with dx, 58624 rows, f32 dy", M * d * 16, lambda: ops.ln_bwd(dyf, x, gamma, mean, rstd, dx_in, dx_out, dg, db, ws))
+    del dyf, dx_in, dx_out
     dkv = r(M, 2 * d).to(BF)
     cs = torch.empty(2 * d, device=DEV)
     cws = torch.empty(ops.colsum_workspace(M, 2 * d), dtype=torch.uint8, device=DEV)
