@@ -184,15 +184,37 @@ def pmc_traffic(span, args, B, whole_vocab):
         on = doc.get("collected_on", {})
         same = (on.get("per_gpu_batch") == B and on.get("dtype") == args.dtype and on.get("n_blocks") == args.n_blocks
                 and on.get("patches") == args.patches and whole_vocab and not args.all_rows)
-        rec = doc.get("launches", {}).get(span)
+        rec = doc.get("launches", {}).get("logits_ce_fwd" if span == "logits_ce_fwd_kernel" else span)     # the counters are per kernel
         return rec["hbm_bytes_per_launch"] if same and rec else None
     return None
 
 
-KERNEL_NAMES = {"logits_ce_fwd": "head_fwd_kernel<2,4,8,4,true,false> (persistent logits+CE forward, 256x256 tiles) + ce_finalize_kernel + ce_reduce_kernel",
+KERNEL_NAMES = {"logits_ce_fwd_kernel": "head_fwd_kernel<2,4,8,4,true,false> (persistent fused logits+CE forward, 256x256 tiles; bracketed alone)",
+                "logits_ce_fwd": "capdec_logits_ce_fwd as a whole: head_fwd_kernel + ce_finalize_kernel + ce_reduce_kernel",
                 "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,2,8,3> (EPI_CE_BWD, 256x128 tiles) + colpart_reduce_kernel",
                 "head_dgrad_slab": "gemm_bf16_pipe_kernel<false,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128, split-K) + splitk_reduce_kernel",
                 "head_wgrad_slab": "gemm_bf16_pipe_kernel<true,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128)"}
+
+
+def head_kernel_timing(on):
+    """HIP event brackets the library puts around the logits+CE forward kernel alone (the engine's bracket of that
+    stage also covers the finalize and loss-sum launches that follow it).  on=False: (launches, mean ms) collected."""
+    import ctypes
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, "capdecdbg_head_fwd_timing"):
+        return None
+    lib.capdecdbg_head_fwd_timing.argtypes = [ctypes.c_int]
+    lib.capdecdbg_head_fwd_timing.restype = None
+    lib.capdecdbg_head_fwd_timing_read.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.capdecdbg_head_fwd_timing_read.restype = ctypes.c_int
+    if on:
+        lib.capdecdbg_head_fwd_timing(1)
+        return None
+    total = ctypes.c_double(0.0)
+    n = lib.capdecdbg_head_fwd_timing_read(ctypes.byref(total))
+    lib.capdecdbg_head_fwd_timing(0)
+    return (n, total.value / n) if n > 0 else None
 
 
 def head_roofline(spans, steps, B, slab, dtype):
@@ -212,7 +234,7 @@ def head_roofline(spans, steps, B, slab, dtype):
                                  "algorithmic_gb": round(nbytes / 1e9, 3), "gb_per_s": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                  "frac_of_8tb_s": round(nbytes / (ms * 1e-3) / 8e12, 3)}
         if name in KERNEL_NAMES:
-            f = 2.0 * Mh * d * V / (1 if name == "logits_ce_fwd" else nslab)      # the last slab is narrower: mean slab width
+            f = 2.0 * Mh * d * V / (1 if name.startswith("logits_ce_fwd") else nslab)      # the last slab is narrower: mean slab width
             per_kernel[name] = {"launches_per_step": count // max(1, steps), "ms_per_launch": round(ms, 4),
                                 "tflops": round(f / (ms * 1e-3) / 1e12, 1)}
     return per_kernel, hbm_kernels
@@ -283,6 +305,7 @@ def main():
         timer = KernelTimer()
         if spans_wanted:
             model.engine.timer = timer
+            head_kernel_timing(True)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -290,11 +313,15 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         model.engine.timer = None
+        hk = head_kernel_timing(False) if spans_wanted else None
         if world > 1 or rehearse:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, out, timer.summary()
+        spans = timer.summary()
+        if hk is not None:
+            spans["logits_ce_fwd_kernel"] = hk
+        return elapsed, out, spans
 
     if args.scaled_only:
         print(json.dumps({"scaled": scaled_bench(build, timed, args)}), flush=True)
@@ -330,7 +357,9 @@ def main():
         # ---- roofline of the dominant kernel: the vocabulary-sized GEMMs of the fused logits+CE stage
         per_kernel, hbm_kernels = head_roofline(spans, args.steps, B, slab, args.dtype)
         blocks_ms = {k: round(ms * c / args.steps, 4) for k, (c, ms) in spans.items() if k.startswith(("block_", "join_"))}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_launch"] * per_kernel[k]["launches_per_step"]) if per_kernel else None
+        # the forward stage's bracket is the kernel's plus two small launches: the kernel's own entry stands for it
+        cand = [k for k in per_kernel if not (k == "logits_ce_fwd" and "logits_ce_fwd_kernel" in per_kernel)]
+        dom = max(cand, key=lambda k: per_kernel[k]["ms_per_launch"] * per_kernel[k]["launches_per_step"]) if cand else None
         roofline = None
         if dom:
             a = per_kernel[dom]["tflops"]

@@ -314,6 +314,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
     }
 }
 
+// Diagnostic (not part of the declared ABI): event brackets around the kernel alone, for a benchmark that wants this
+// launch's duration without the finalize pass that follows it in the same entry point.
+constexpr int TIMING_PAIRS = 512;
+struct LaunchTiming { bool on = false; int n = 0; hipEvent_t ev[2 * TIMING_PAIRS] = {}; bool made = false; } g_timing;
+
 template <int WM, int WN, int TI, int NST>
 int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
     using G = Geo<WM, WN, TI, NST>;
@@ -331,7 +336,10 @@ int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (nseen < 8) seen[nseen++] = (const void*)kfn;
         }
+        const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS;
+        if (timing) (void)hipEventRecord(g_timing.ev[2 * g_timing.n], st);
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * G::NW), G::LDS, st, a);
+        if (timing) { (void)hipEventRecord(g_timing.ev[2 * g_timing.n + 1], st); ++g_timing.n; }
     };
     if (a.stamps) {                                       // diagnostic build of the same kernel: clock stamps per workgroup
         if (a.C) go(head_fwd_kernel<WM, WN, TI, NST, true, true>);
@@ -343,6 +351,27 @@ int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// on != 0: start collecting (up to 512 launches on the current device); on == 0: stop
+extern "C" void capdecdbg_head_fwd_timing(int on) {
+    if (on && !g_timing.made) {
+        bool ok = true;
+        for (int i = 0; i < 2 * TIMING_PAIRS && ok; ++i) ok = hipEventCreate(&g_timing.ev[i]) == hipSuccess;
+        g_timing.made = ok;
+    }
+    g_timing.on = on != 0;
+    if (on) g_timing.n = 0;
+}
+// sum of the collected durations in ms (call after synchronising the stream); returns the number of launches
+extern "C" int capdecdbg_head_fwd_timing_read(double* total_ms) {
+    double t = 0.0;
+    for (int i = 0; i < g_timing.n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_timing.ev[2 * i], g_timing.ev[2 * i + 1]) == hipSuccess) t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    return g_timing.n;
+}
 
 bool head_fwd_supported(const HeadFwdArgs& a) {
     return a.K >= 8 * DBK && (a.K % DBK) == 0 && (a.lda % 8) == 0 && (a.ldb % 8) == 0 && aligned16(a.A) && aligned16(a.B) &&
