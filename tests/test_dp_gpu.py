@@ -17,11 +17,13 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0):
+def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)              # RCCL: one GPU per rank
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import helpers as H
         from image_caption_amd.decoder import CaptionTrainer, TransformerDecoder
@@ -60,6 +62,8 @@ def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0):
             flat = torch.cat([got[k].reshape(-1) for k in sorted(got)])
             seeds = [None] * world
             dist.all_gather_object(seeds, seed)
+            if backend == "nccl":
+                flat = flat.cuda()
             both = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(both, flat)
             if len(set(seeds)) != world:
@@ -95,6 +99,22 @@ def test_two_rank_training_matches_single_process(dtype_name, batch, dropout):
     q = ctx.Queue()
     port = 29950 + (os.getpid() % 40) + (0 if dtype_name == "float32" else 1) + 2 * batch + (50 if dropout else 0)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, q, batch, dropout)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs")
+@pytest.mark.parametrize("dtype_name,batch,dropout", [("float32", 6, 0.0), ("bfloat16", 5, 0.0), ("float32", 6, 0.1)])
+def test_two_rank_training_over_rccl(dtype_name, batch, dropout):
+    """The same comparison with one GPU per rank and the gradient buckets reduced by RCCL."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29890 + (os.getpid() % 40) + (0 if dtype_name == "float32" else 1) + 2 * batch + (50 if dropout else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, q, batch, dropout, "nccl")) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
