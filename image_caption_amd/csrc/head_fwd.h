@@ -1,4 +1,5 @@
-// Persistent fused logits + cross-entropy forward (bf16, row-major operands): arguments and launcher.
+// Persistent bf16 product C = epilogue(A B^T + bias) with row-major operands: arguments and launcher.
+// mode 0: fused logits + cross-entropy forward; mode 1: bias / column scale / ReLU / dropout, bf16 output.
 #pragma once
 #include "common.h"
 
@@ -13,6 +14,11 @@ struct HeadFwdArgs {
     f32x4* part4;         // [np slots][M rows] of {reference value, sum exp(z - reference), -inf, argmax as int bits}
     int np;
     unsigned long long* stamps;   // diagnostic: 8 words per workgroup, NULL in normal use
+    // mode 1 (C required, part4 unused): y = dropout(relu?((z + bias) * (column < col_scale_n ? col_scale : 1)))
+    int mode;
+    float col_scale; int col_scale_n;     // col_scale_n a multiple of 64
+    int relu;
+    unsigned drop_thr, drop_k0, drop_k1; float drop_scale;      // thr 0: off; element index m * N + n
 };
 
 // geometry 0: 256x128 tiles, 4 waves, two workgroups per CU; 1: 256x256 tiles, 8 waves, one workgroup per CU

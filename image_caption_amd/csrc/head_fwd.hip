@@ -97,7 +97,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, t);
 }
 
-template <int WM, int WN, int TI, int NST, bool KEEP, bool STAMPS>
+template <int WM, int WN, int TI, int NST, bool KEEP, bool STAMPS, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) void head_fwd_kernel(HeadFwdArgs p) {
     using G = Geo<WM, WN, TI, NST>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b = *reinterpret_cast<const f32x4*>(smem + G::RING + sel * G::BIAS_BYTES + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : PAST;
+            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : (MODE == 1 ? 0.f : PAST);
         }
     };
 
@@ -259,28 +259,47 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
-            // maximum with the column riding in the low mantissa bits: column 16j + 4q + e, stored complemented so
-            // that among (nearly) equal positive values the lowest column wins
-            float pm = 0.f;
+            if constexpr (MODE == 1) {
+                // standard epilogue: column scale (uniform per 64-column wave tile), ReLU, dropout on the element index m * N + n
+                const float sc = nw < p.col_scale_n ? p.col_scale : 1.f;
+                const float fl = p.relu ? 0.f : -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const unsigned c = (unsigned)(((3 - (t >> 2)) << 4) | (3 - (t & 3)));
-                const float f = __uint_as_float((__float_as_uint(v[t]) & 0xFFFFFFC0u) | c);
-                pm = t == 0 ? f : fmaxf(pm, f);
-            }
-            pm = quad_max(__uint_as_float(__float_as_uint(pm) | qbits));
-            const float nref = pm > -1.0e38f ? -pm * LOG2E : 0.f;      // a slot wholly past N: numerators exp2(-inf) = 0
-            float sum = 0.f;
+                for (int t = 0; t < 16; ++t) v[t] = fmaxf(v[t] * sc, fl);
+                if (p.drop_thr) {
+                    const unsigned base = (unsigned)((long)(mb + r16) * p.N + nw + 4 * q);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { v[t] = __builtin_amdgcn_exp2f(fmaf(v[t], LOG2E, nref)); sum += v[t]; }
-            sum = quad_sum(sum);
-            if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
-            {
-                const int arg = nw + 63 - (int)(__float_as_uint(pm) & 63u);
-                const f32x4 rec = {pm, sum, -INFINITY, __int_as_float(arg)};
-                const __amdgpu_buffer_rsrc_t prs = rsrc_at((const char*)(p.part4 + ((long)slot * p.M + mb)), 0xFFFFFFF0L);
-                const unsigned off = (q == 0 && row_ok && slot_ok) ? (unsigned)(r16 * 16) : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), prs, off, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        bool keep[4];
+                        dropout_keep4(p.drop_k0, p.drop_k1, base + 16 * j, p.drop_thr, keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * j + e] = keep[e] ? v[4 * j + e] * p.drop_scale : 0.f;
+                    }
+                }
+                if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
+            } else {
+                // maximum with the column riding in the low mantissa bits: column 16j + 4q + e, stored complemented so
+                // that among (nearly) equal positive values the lowest column wins
+                float pm = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const unsigned c = (unsigned)(((3 - (t >> 2)) << 4) | (3 - (t & 3)));
+                    const float f = __uint_as_float((__float_as_uint(v[t]) & 0xFFFFFFC0u) | c);
+                    pm = t == 0 ? f : fmaxf(pm, f);
+                }
+                pm = quad_max(__uint_as_float(__float_as_uint(pm) | qbits));
+                const float nref = pm > -1.0e38f ? -pm * LOG2E : 0.f;      // a slot wholly past N: numerators exp2(-inf) = 0
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { v[t] = __builtin_amdgcn_exp2f(fmaf(v[t], LOG2E, nref)); sum += v[t]; }
+                sum = quad_sum(sum);
+                if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
+                {
+                    const int arg = nw + 63 - (int)(__float_as_uint(pm) & 63u);
+                    const f32x4 rec = {pm, sum, -INFINITY, __int_as_float(arg)};
+                    const __amdgpu_buffer_rsrc_t prs = rsrc_at((const char*)(p.part4 + ((long)slot * p.M + mb)), 0xFFFFFFF0L);
+                    const unsigned off = (q == 0 && row_ok && slot_ok) ? (unsigned)(r16 * 16) : 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), prs, off, 0, 0);
+                }
             }
             if constexpr (KEEP) {
                 const __amdgpu_buffer_rsrc_t crs = rsrc_at((const char*)(p.C + (long)mb * p.ldc + nw), 0xFFFFFFF0L);
@@ -336,12 +355,13 @@ int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (nseen < 8) seen[nseen++] = (const void*)kfn;
         }
-        const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS;
+        const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS && a.mode == 0 && a.C;      // the training forward only
         if (timing) (void)hipEventRecord(g_timing.ev[2 * g_timing.n], st);
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * G::NW), G::LDS, st, a);
         if (timing) { (void)hipEventRecord(g_timing.ev[2 * g_timing.n + 1], st); ++g_timing.n; }
     };
-    if (a.stamps) {                                       // diagnostic build of the same kernel: clock stamps per workgroup
+    if (a.mode == 1) go(head_fwd_kernel<WM, WN, TI, NST, true, false, 1>);
+    else if (a.stamps) {                                  // diagnostic build of the same kernel: clock stamps per workgroup
         if (a.C) go(head_fwd_kernel<WM, WN, TI, NST, true, true>);
         else go(head_fwd_kernel<WM, WN, TI, NST, false, true>);
     } else if (a.C) go(head_fwd_kernel<WM, WN, TI, NST, true, false>);
@@ -374,6 +394,7 @@ extern "C" int capdecdbg_head_fwd_timing_read(double* total_ms) {
 }
 
 bool head_fwd_supported(const HeadFwdArgs& a) {
+    if (a.mode == 1 && (!a.C || (a.col_scale_n % 64) != 0 || (a.N % 8) != 0 || a.store_cols != a.N)) return false;
     return a.K >= 8 * DBK && (a.K % DBK) == 0 && (a.lda % 8) == 0 && (a.ldb % 8) == 0 && aligned16(a.A) && aligned16(a.B) &&
            (!a.C || ((a.ldc % 8) == 0 && (a.store_cols % 8) == 0 && aligned16(a.C))) &&
            (long)a.np * a.M * 16 < 0xFFFFFFF0L && 256L * a.lda * 2 < 0x7FFFFFFFL && 256L * a.ldb * 2 < 0x7FFFFFFFL &&

@@ -19,7 +19,6 @@ extern "C" int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
 namespace {
 
 constexpr int LN_MAX_D = 2048;        // 8 x float4 per lane
-constexpr int LN_VEC = LN_MAX_D / 256;
 
 template <typename T>
 __device__ __forceinline__ f32x4 load4(const T* p);

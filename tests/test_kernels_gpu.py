@@ -128,6 +128,44 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     close(dbias, ref_dl.sum(0), 1e-2, "dbias")
 
 
+@pytest.mark.parametrize("M,N,K,relu,p,scale_n", [
+    (515, 640, 768, True, 0.1, 0),            # ragged rows, several tiles
+    (1000, 2056, 256, False, 0.0, 0),         # N a multiple of 8 only: the last tile's columns end inside a 64-column wave tile
+    (300, 2304, 288, False, 0.2, 768),        # column scale on the first 768 columns (the query part of in_proj), 9 k-steps
+    (8192, 2304, 768, True, 0.1, 768),        # more tiles than workgroups
+])
+def test_persistent_standard_epilogue(gemm_mode, M, N, K, relu, p, scale_n):
+    """The persistent kernel's bias / column-scale / ReLU / dropout epilogue (mode 10 forces it) against the tile
+    kernels (mode 4) and torch: same dropout mask element for element, values within bf16 rounding."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=95)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=96)
+    bias = rnd(N, seed=97)
+    drop = ops.dropout_keys(5, 6, 7, p) if p > 0 else _lib.NO_DROPOUT
+    kw = dict(bias=bias, act=_lib.ACT_RELU if relu else _lib.ACT_NONE, drop=drop, col_scale=0.25, col_scale_n=scale_n)
+    outs = []
+    for mode in (10, 4):
+        out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        gemm_mode(mode)
+        ops.gemm(A, B, out, **kw)
+        gemm_mode(0)
+        outs.append(out.float())
+    z = A.float() @ B.float().t() + bias
+    if scale_n:
+        z[:, :scale_n] *= 0.25
+    if relu:
+        z = torch.relu(z)
+    kept = outs[1] != 0 if p > 0 else torch.ones_like(z, dtype=torch.bool)
+    ref = torch.where(kept, z / (1.0 - p), torch.zeros_like(z))
+    assert bool(torch.isfinite(outs[0]).all())
+    if p > 0:
+        # the two kernels regenerate the same mask: zeros in the same places wherever the value itself is not zero
+        nz = ref != 0
+        assert torch.equal((outs[0] != 0) & nz, (outs[1] != 0) & nz)
+        assert abs(float(kept.float().mean()) - (1.0 - p) * (float((z != 0).float().mean()) if relu else 1.0)) < 0.02
+    close(outs[0], ref, 1.5e-2, "persistent vs torch")
+    close(outs[0], outs[1], 1e-2, "persistent vs tile kernel")
+
+
 @pytest.mark.parametrize("mode", [8, 9])              # the two tile geometries of the persistent forward kernel
 @pytest.mark.parametrize("B_,L,V,d,with_bias", [
     (5, 8, 1111, 256, True),            # one ragged tile in M, ragged in N
