@@ -1811,19 +1811,30 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     }
     // Large row-major bf16 products with nothing but bias / column scale / ReLU / dropout behind them (the in_proj and
     // linear1 forwards of a stack at full batch) go to the persistent kernel of head_fwd.hip: one operand ring for the
-    // whole launch, epilogue on the accumulator registers.  Diagnostic mode 10 forces it at any size, any other
-    // non-zero mode keeps the tile kernels.
+    // whole launch, epilogue on the accumulator registers.  Diagnostic modes 10 / 11 force it at any size (256x256 /
+    // 256x128 tiles), any other non-zero mode keeps the tile kernels.
     if (d->in_dtype == CAPDEC_BF16 && a.out_dtype == CAPDEC_BF16 && !a.a_kmajor && !a.b_kmajor && !a.residual && !a.accumulate &&
         a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache &&
         (a.act == CAPDEC_ACT_NONE || a.act == CAPDEC_ACT_RELU) &&
-        (g_gemm_mode == 10 || (g_gemm_mode == 0 && (long)a.M * a.N >= (1L << 25) && a.K <= 1024))) {
+        (g_gemm_mode == 10 || g_gemm_mode == 11 || (g_gemm_mode == 0 && (long)a.M * a.N >= (1L << 25) && a.K <= 1024))) {
         HeadFwdArgs ha = {};
         ha.A = (const bf16_t*)a.A; ha.B = (const bf16_t*)a.B; ha.bias = a.bias; ha.C = (bf16_t*)a.C;
         ha.lda = a.lda; ha.ldb = a.ldb; ha.ldc = a.ldc; ha.M = a.M; ha.N = a.N; ha.K = a.K; ha.store_cols = a.N;
         ha.mode = 1; ha.col_scale = a.col_scale_n > 0 ? a.col_scale : 1.f; ha.col_scale_n = a.col_scale_n;
         ha.relu = a.act == CAPDEC_ACT_RELU;
         ha.drop_thr = a.drop_thr; ha.drop_k0 = a.drop_k0; ha.drop_k1 = a.drop_k1; ha.drop_scale = a.drop_scale;
-        if (head_fwd_supported(ha)) return head_fwd_launch(ha, 1, (hipStream_t)stream);
+        if (head_fwd_supported(ha)) return head_fwd_launch(ha, g_gemm_mode == 11 ? 0 : 1, (hipStream_t)stream);
+    }
+    // ... and those that add a dropped-out product to an f32 residual stream (the out_proj and linear2 forwards)
+    if (d->in_dtype == CAPDEC_BF16 && a.out_dtype == CAPDEC_F32 && !a.a_kmajor && !a.b_kmajor && a.residual && !a.accumulate &&
+        a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache && a.act == CAPDEC_ACT_NONE && a.col_scale_n == 0 &&
+        (g_gemm_mode == 10 || g_gemm_mode == 11 || (g_gemm_mode == 0 && (long)a.M * a.N >= (1L << 25)))) {
+        HeadFwdArgs ha = {};
+        ha.A = (const bf16_t*)a.A; ha.B = (const bf16_t*)a.B; ha.bias = a.bias; ha.Cf = (float*)a.C; ha.residual = a.residual;
+        ha.lda = a.lda; ha.ldb = a.ldb; ha.ldc = a.ldc; ha.ldr = a.ldr; ha.M = a.M; ha.N = a.N; ha.K = a.K; ha.store_cols = a.N;
+        ha.mode = 2;
+        ha.drop_thr = a.drop_thr; ha.drop_k0 = a.drop_k0; ha.drop_k1 = a.drop_k1; ha.drop_scale = a.drop_scale;
+        if (head_fwd_supported(ha)) return head_fwd_launch(ha, g_gemm_mode == 11 ? 0 : 1, (hipStream_t)stream);
     }
     // straight-line epilogue: bias / column scale / ReLU / dropout only, every lane's 16-byte group of columns
     // aligned and entirely inside or outside N

@@ -1,5 +1,6 @@
 // Persistent bf16 product C = epilogue(A B^T + bias) with row-major operands: arguments and launcher.
-// mode 0: fused logits + cross-entropy forward; mode 1: bias / column scale / ReLU / dropout, bf16 output.
+// mode 0: fused logits + cross-entropy forward; mode 1: bias / column scale / ReLU / dropout, bf16 output;
+// mode 2: residual + dropout(z + bias), f32 output.
 #pragma once
 #include "common.h"
 
@@ -19,6 +20,8 @@ struct HeadFwdArgs {
     float col_scale; int col_scale_n;     // col_scale_n a multiple of 64
     int relu;
     unsigned drop_thr, drop_k0, drop_k1; float drop_scale;      // thr 0: off; element index m * N + n
+    // mode 2 (C is the f32 output [M, ldc], given through Cf; C itself unused): y = residual + dropout(z + bias)
+    float* Cf; const float* residual; long ldr;
 };
 
 // geometry 0: 256x128 tiles, 4 waves, two workgroups per CU; 1: 256x256 tiles, 8 waves, one workgroup per CU

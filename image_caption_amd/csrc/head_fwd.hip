@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b = *reinterpret_cast<const f32x4*>(smem + G::RING + sel * G::BIAS_BYTES + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : (MODE == 1 ? 0.f : PAST);
+            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : (MODE != 0 ? 0.f : PAST);
         }
     };
 
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         // stores: one descriptor per 16-row block (scalar arithmetic), one lane offset for all of them; a lane whose row or
         // columns do not exist gets an offset no descriptor holds, and the store is dropped -- but always issued
         const bool slot_ok = slot < p.np;
+        f32x4 res_buf[MODE == 2 ? 2 : 1][4];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int mb = mw + i * 16;                      // first row of the block
@@ -259,7 +260,43 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 2) {
+                // residual + dropout(z + bias) -> f32: the lane's 4 consecutive columns of each 16-column tile are one
+                // 16-byte load and one 16-byte store
+                const __amdgpu_buffer_rsrc_t ors = rsrc_at((const char*)(p.Cf + (long)mb * p.ldc + nw), 0xFFFFFFF0L);
+                // the residual rows of a block are requested one block ahead of their use (deeper made no difference)
+                auto load_res = [&](int ii, f32x4 (&dst)[4]) {
+                    const int mbb = mw + ii * 16;
+                    const __amdgpu_buffer_rsrc_t rr = rsrc_at((const char*)(p.residual + (long)mbb * p.ldr + nw), 0xFFFFFFF0L);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = r16 < p.M - mbb && 16 * j + 4 * q < p.N - nw;
+                        const unsigned off = ok ? (unsigned)(((long)r16 * p.ldr + 16 * j + 4 * q) * 4) : 0xFFFFFFFFu;
+                        dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
+                    }
+                };
+                if (i == 0) load_res(0, res_buf[0]);
+                if (i + 1 < TI) load_res(i + 1, res_buf[(i + 1) & 1]);
+                f32x4 (&rv)[4] = res_buf[i & 1];
+                if (p.drop_thr) {
+                    const unsigned base = (unsigned)((long)(mb + r16) * p.N + nw + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool keep[4];
+                        dropout_keep4(p.drop_k0, p.drop_k1, base + 16 * j, p.drop_thr, keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * j + e] = keep[e] ? v[4 * j + e] * p.drop_scale : 0.f;
+                    }
+                }
+                if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = row_ok && 16 * j + 4 * q < p.N - nw;
+                    const unsigned off = ok ? (unsigned)(((long)r16 * p.ldc + 16 * j + 4 * q) * 4) : 0xFFFFFFFFu;
+                    const f32x4 o = {v[4 * j] + rv[j][0], v[4 * j + 1] + rv[j][1], v[4 * j + 2] + rv[j][2], v[4 * j + 3] + rv[j][3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
+                }
+            } else if constexpr (MODE == 1) {
                 // standard epilogue: column scale (uniform per 64-column wave tile), ReLU, dropout on the element index m * N + n
                 const float sc = nw < p.col_scale_n ? p.col_scale : 1.f;
                 const float fl = p.relu ? 0.f : -INFINITY;
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), prs, off, 0, 0);
                 }
             }
-            if constexpr (KEEP) {
+            if constexpr (KEEP && MODE != 2) {
                 const __amdgpu_buffer_rsrc_t crs = rsrc_at((const char*)(p.C + (long)mb * p.ldc + nw), 0xFFFFFFF0L);
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
@@ -360,7 +397,8 @@ int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * G::NW), G::LDS, st, a);
         if (timing) { (void)hipEventRecord(g_timing.ev[2 * g_timing.n + 1], st); ++g_timing.n; }
     };
-    if (a.mode == 1) go(head_fwd_kernel<WM, WN, TI, NST, true, false, 1>);
+    if (a.mode == 2) go(head_fwd_kernel<WM, WN, TI, NST, false, false, 2>);
+    else if (a.mode == 1) go(head_fwd_kernel<WM, WN, TI, NST, true, false, 1>);
     else if (a.stamps) {                                  // diagnostic build of the same kernel: clock stamps per workgroup
         if (a.C) go(head_fwd_kernel<WM, WN, TI, NST, true, true>);
         else go(head_fwd_kernel<WM, WN, TI, NST, false, true>);
@@ -395,6 +433,8 @@ extern "C" int capdecdbg_head_fwd_timing_read(double* total_ms) {
 
 bool head_fwd_supported(const HeadFwdArgs& a) {
     if (a.mode == 1 && (!a.C || (a.col_scale_n % 64) != 0 || (a.N % 8) != 0 || a.store_cols != a.N)) return false;
+    if (a.mode == 2 && (a.C || !a.Cf || !a.residual || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ldr % 4) != 0 || !aligned16(a.Cf) ||
+                        !aligned16(a.residual) || 256L * a.ldc * 4 >= 0x7FFFFFFFL || 256L * a.ldr * 4 >= 0x7FFFFFFFL)) return false;
     return a.K >= 8 * DBK && (a.K % DBK) == 0 && (a.lda % 8) == 0 && (a.ldb % 8) == 0 && aligned16(a.A) && aligned16(a.B) &&
            (!a.C || ((a.ldc % 8) == 0 && (a.store_cols % 8) == 0 && aligned16(a.C))) &&
            (long)a.np * a.M * 16 < 0xFFFFFFF0L && 256L * a.lda * 2 < 0x7FFFFFFFL && 256L * a.ldb * 2 < 0x7FFFFFFFL &&

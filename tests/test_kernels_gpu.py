@@ -134,8 +134,9 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     (300, 2304, 288, False, 0.2, 768),        # column scale on the first 768 columns (the query part of in_proj), 9 k-steps
     (8192, 2304, 768, True, 0.1, 768),        # more tiles than workgroups
 ])
-def test_persistent_standard_epilogue(gemm_mode, M, N, K, relu, p, scale_n):
-    """The persistent kernel's bias / column-scale / ReLU / dropout epilogue (mode 10 forces it) against the tile
+@pytest.mark.parametrize("pmode", [10, 11])           # 256x256 and 256x128 tiles
+def test_persistent_standard_epilogue(gemm_mode, pmode, M, N, K, relu, p, scale_n):
+    """The persistent kernel's bias / column-scale / ReLU / dropout epilogue (modes 10 / 11 force it) against the tile
     kernels (mode 4) and torch: same dropout mask element for element, values within bf16 rounding."""
     A = rnd(M, K, dtype=torch.bfloat16, seed=95)
     B = rnd(N, K, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=96)
@@ -143,7 +144,7 @@ def test_persistent_standard_epilogue(gemm_mode, M, N, K, relu, p, scale_n):
     drop = ops.dropout_keys(5, 6, 7, p) if p > 0 else _lib.NO_DROPOUT
     kw = dict(bias=bias, act=_lib.ACT_RELU if relu else _lib.ACT_NONE, drop=drop, col_scale=0.25, col_scale_n=scale_n)
     outs = []
-    for mode in (10, 4):
+    for mode in (pmode, 4):
         out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         gemm_mode(mode)
         ops.gemm(A, B, out, **kw)
@@ -164,6 +165,35 @@ def test_persistent_standard_epilogue(gemm_mode, M, N, K, relu, p, scale_n):
         assert abs(float(kept.float().mean()) - (1.0 - p) * (float((z != 0).float().mean()) if relu else 1.0)) < 0.02
     close(outs[0], ref, 1.5e-2, "persistent vs torch")
     close(outs[0], outs[1], 1e-2, "persistent vs tile kernel")
+
+
+@pytest.mark.parametrize("mode", [10, 11])            # 256x256 and 256x128 tiles of the persistent kernel
+@pytest.mark.parametrize("M,N,K,p", [
+    (515, 768, 768, 0.1),            # out_proj shape: three column tiles, ragged rows
+    (1000, 260, 2048, 0.0),          # N a multiple of 4 only, deep reduction (linear2)
+    (8192, 768, 2048, 0.1),          # more tiles than workgroups
+])
+def test_persistent_residual_epilogue(gemm_mode, mode, M, N, K, p):
+    """y = residual + dropout(x W^T + b) in f32 from the persistent kernel against the tile kernels and torch."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=101)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=102)
+    bias, res = rnd(N, seed=103), rnd(M, N, seed=104)
+    drop = ops.dropout_keys(8, 9, 10, p) if p > 0 else _lib.NO_DROPOUT
+    outs = []
+    for md in (mode, 4):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        gemm_mode(md)
+        ops.gemm(A, B, out, bias=bias, drop=drop, residual=res)
+        gemm_mode(0)
+        outs.append(out)
+    z = A.float() @ B.float().t() + bias
+    kept = (outs[1] - res).abs() > 1e-7 if p > 0 else torch.ones_like(z, dtype=torch.bool)
+    ref = res + torch.where(kept, z / (1.0 - p), torch.zeros_like(z))
+    assert bool(torch.isfinite(outs[0]).all())
+    if p > 0:
+        assert torch.equal((outs[0] - res).abs() > 1e-7, kept)       # the same mask, element for element
+    close(outs[0], ref, 1.5e-2, "persistent vs torch")
+    close(outs[0], outs[1], 1e-3, "persistent vs tile kernel")
 
 
 @pytest.mark.parametrize("mode", [8, 9])              # the two tile geometries of the persistent forward kernel
