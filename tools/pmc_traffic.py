@@ -16,7 +16,7 @@ import sys
 
 # span name in bench.py -> (kernel template arguments, workgroups) at batch 256, V = 50260, d = 768
 LAUNCHES = {
-    "logits_ce_fwd": ("head_fwd_kernel<2, 4, 8, 4, true, false>", None),
+    "logits_ce_fwd": ("head_fwd_kernel<2, 4, 8, 4, true, false, 0>", None),
     "logits_ce_bwd_slab": ("gemm_bf16_dma_kernel<false, false, 2, 2, 2, 8, 3>", None),
     "head_wgrad_slab": ("gemm_bf16_pipe_kernel<true, true, 0, 8>", 197 * 3 * 256),
     "head_dgrad_slab": ("gemm_bf16_pipe_kernel<false, true, 0, 8>", 32 * 3 * 8 * 256),
