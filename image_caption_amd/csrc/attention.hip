@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(At
 // ================================================================== backward: dQ (query-major)
 // SEQ as in the forward: one workgroup of 8 waves per (sequence, head), K and V both in LDS.
 template <int HD, bool SEQ>
-__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dq_mfma(AttnArgs p) {
+__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -458,28 +458,61 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dq_mfma
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
 
+    // SEQ: the K and V fragments of a 16-key tile are read from the LDS images one tile ahead of their products (two
+    // register sets), K's transposed fragments for the dQ products during the block's second half: left to the compiler,
+    // every LDS read sits directly in front of its MFMA and is waited for there
+    bf16x8 kfr[2][G::KS], vfr[2][G::KS];
+    auto read_rows = [&](int key0, int set) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            kfr[set][ks] = frag_rows<HD>(Kl, key0, ks * 32, lane);
+            vfr[set][ks] = frag_rows<HD>(Vl, key0, ks * 32, lane);
+        }
+    };
+    if constexpr (SEQ) read_rows(0, 0);
     for (int kb = 0; kb < SP; kb += 64) {
-        bf16x8 dsf[2];
+        u32x4 dsu[2];
+        bf16x8 kcf[SEQ ? 2 : 1][SEQ ? G::DT : 1];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 s = f32x4{0, 0, 0, 0}, dp = f32x4{0, 0, 0, 0};
+            if constexpr (SEQ) {
+                if (t < 3) read_rows(kb + (t + 1) * 16, (t + 1) & 1);
+                else if (kb + 64 < SP) read_rows(kb + 64, 0);
+                if (t == 2) {
+#pragma unroll
+                    for (int dt = 0; dt < G::DT; ++dt) kcf[0][dt] = frag_cols<HD>(Kl, kb, kb + 16, dt * 16, lane);
+                }
+                if (t == 3) {
+#pragma unroll
+                    for (int dt = 0; dt < G::DT; ++dt) kcf[1][dt] = frag_cols<HD>(Kl, kb + 32, kb + 48, dt * 16, lane);
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
-                if constexpr (SEQ) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Vl, kb + t * 16, ks * 32, lane), dof[ks], dp, 0, 0, 0);
-                else dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
+                if constexpr (SEQ) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[t & 1][ks], qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[t & 1][ks], dof[ks], dp, 0, 0, 0);
+                } else {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
+                }
             }
             bool keep[4] = {true, true, true, true};
             if (p.drop_thr) dropout_keep4(p.drop_k0, p.drop_k1, idx_row + kb + t * 16 + 4 * g, p.drop_thr, keep);
             const bool masked = kb + 64 > klim_wave;          // wave-uniform: some query of the wave does not see the whole block
+            float dsv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pv = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nlse2));
                 if (masked) pv = kb + t * 16 + 4 * g + r < klim ? pv : 0.f;
                 const float dpv = keep[r] ? dp[r] * p.drop_scale : 0.f;
-                dsf[t >> 1][(t & 1) * 4 + r] = (bf16_t)(pv * (dpv - delta));
+                dsv[r] = pv * (dpv - delta);
             }
+            dsu[t >> 1][(t & 1) * 2 + 0] = pack_bf16(dsv[0], dsv[1]);
+            dsu[t >> 1][(t & 1) * 2 + 1] = pack_bf16(dsv[2], dsv[3]);
         }
+        const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, dsu[0]), __builtin_bit_cast(bf16x8, dsu[1])};
         if constexpr (!SEQ) {
             // the next key block of V replaces the fragments just consumed; the dS K products below cover the latency
             if (kb + 64 < SP) frags_from_global<HD>(vbase, p.v_ss, kb + 64, p.S, lane, vf);
@@ -487,9 +520,11 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dq_mfma
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
-                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
+            for (int dt = 0; dt < G::DT; ++dt) {
+                if constexpr (SEQ) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf[st][dt], dsf[st], acc[dt], 0, 0, 0);
+                else acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
+            }
     }
     if (qok) {
         bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
