@@ -1344,7 +1344,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_WIDE;
         else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
-        else if (g_gemm_mode == 7 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_TALLP;
+        else if (g_gemm_mode == 7 && ring_ok && (EPI == EPI_STD || !any_km || (EPI == EPI_STD_SIDE && !a.a_kmajor))) kern = KERN_TALLP;
         else if (g_gemm_mode == 2 && ring_ok) kern = KERN_RING128;
         else if (g_gemm_mode == 3 && ring_ok && !any_km) kern = KERN_BIG;
         else if (g_gemm_mode == 4 && ring_ok) kern = KERN_TALL;
@@ -1390,6 +1390,9 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
                 else if (a.a_kmajor) CAPDEC_PIPE_LAUNCH(true, false, EPI_STD, 4, big_tiles);
                 else if (a.b_kmajor) CAPDEC_PIPE_LAUNCH(false, true, EPI_STD, 4, big_tiles);
                 else CAPDEC_PIPE_LAUNCH(false, false, EPI_STD, 4, big_tiles);
+            } else if constexpr (EPI == EPI_STD_SIDE) {
+                if (a.b_kmajor) CAPDEC_PIPE_LAUNCH(false, true, EPI_STD_SIDE, 4, big_tiles);      // the dgrad through an activation gate
+                else CAPDEC_PIPE_LAUNCH(false, false, EPI_STD_SIDE, 4, big_tiles);
             } else {
                 CAPDEC_PIPE_LAUNCH(false, false, EPI, 4, big_tiles);
             }

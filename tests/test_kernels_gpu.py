@@ -411,6 +411,27 @@ def test_gemm_gates(dtype, tol):
             assert torch.equal(runs[0], runs[1])
 
 
+@pytest.mark.parametrize("mode", [0, 4, 7])
+def test_gated_dgrad_every_geometry(gemm_mode, mode):
+    """The data gradient through linear2 and the ReLU gate as the engine launches it (W reduction-major, gate and dropout
+    applied in the epilogue, bias-gradient column sums through the workspace), on the ring and the pipelined kernels."""
+    M, N, K = 1000, 2048, 768
+    A = rnd(M, K, dtype=torch.bfloat16, seed=111)
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.05, seed=112)
+    saved = torch.relu(rnd(M, N, seed=113)).to(torch.bfloat16)
+    gd = ops.dropout_keys(4, 5, 6, p=0.1)
+    # the saved activation is what came out of ReLU AND dropout: its zeros carry both masks, the keys only the scale
+    want = (A.float() @ B.float()) * (saved.float() != 0) / 0.9
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=DEV)
+    ws = torch.empty((M + 63) // 64 * N * 4, dtype=torch.uint8, device=DEV)
+    gemm_mode(mode)
+    ops.gemm(A, B, out, b_kmajor=True, gate=saved, gate_mode=_lib.GATE_RELU_OUT, gate_drop=gd, colsum=cs, workspace=ws)
+    gemm_mode(0)
+    close(out, want, 1.5e-2, f"mode {mode}")
+    close(cs, want.sum(0), 6e-2, f"mode {mode}: column sums")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_kv_scatter(dtype):
     Bb, H, hd, smax, s0, ns = 3, 2, 32, 10, 4, 2
