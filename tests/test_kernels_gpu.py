@@ -554,6 +554,8 @@ def mask_for(S, mode, prefix):
     (2, 3, 130, 64, _lib.MASK_PREFIX_CAUSAL, 100, 0.1),
     (1, 2, 290, 96, _lib.MASK_NONE, 0, 0.1),
     (1, 1, 200, 128, _lib.MASK_REFERENCE, 0, 0.0),
+    (67, 4, 150, 96, _lib.MASK_PREFIX_CAUSAL, 120, 0.1),    # 268 heads: some persistent workgroups walk two, one ragged last round
+    (130, 4, 90, 64, _lib.MASK_NONE, 0, 0.0),               # 520 heads: every persistent workgroup walks two or three
 ])
 def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
     d = H * hd
