@@ -1742,6 +1742,29 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     CAPDEC_CHECK((long)d->M * d->N < (1L << 32) || (d->drop.p <= 0.f && d->gate_mode != CAPDEC_GATE_GELU_PRE),
                  "gemm: dropout index space exceeds 2^32 elements");
     if (d->M == 0 || d->N == 0) return CAPDEC_OK;
+    // Plain deep-K products on 256x256 tiles whose last round of workgroups would leave most CUs idle (the vocabulary
+    // weight gradient: 591 tiles on 256 CUs = 2.3 rounds billed as 3): the M-tiles of that last round are cut off and
+    // run as a second, split-K product through the workspace -- 2 rounds + 1/3 instead of 3.
+    if (d->in_dtype == CAPDEC_BF16 && g_gemm_mode == 0 && d->workspace && d->K >= 2048 && !d->bias && d->col_scale_n == 0 &&
+        d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual && !d->gate && !d->aux_out && !d->colsum && !d->kv_cache &&
+        ((d->K % 32) == 0 || (d->a_kmajor && d->b_kmajor))) {
+        const long tmw = (d->M + 255) / 256, tnw = (d->N + 255) / 256, wide = tmw * tnw, rem = wide % 256;
+        const long tail_m = (rem + tnw - 1) / tnw, head_m = tmw - tail_m;
+        const long tail_slab = tail_m * 256 * (long)d->N * 4;
+        if (wide > 256 && rem > 0 && rem <= 128 && head_m > 0 && tail_m * tnw <= 128 && d->workspace_bytes >= 2 * tail_slab) {
+            const long m0 = head_m * 256;
+            const long esz = 2, osz = d->out_dtype == CAPDEC_BF16 ? 2 : 4;
+            capdec_gemm_desc h1 = *d, t1 = *d;
+            h1.M = (int)m0;
+            h1.workspace = nullptr; h1.workspace_bytes = 0;
+            t1.M = d->M - (int)m0;
+            t1.A = (const char*)d->A + (d->a_kmajor ? m0 : m0 * d->lda) * esz;
+            t1.C = (char*)d->C + m0 * d->ldc * osz;
+            int rc = capdec_gemm_bias_act(&h1, stream);
+            if (rc) return rc;
+            return capdec_gemm_bias_act(&t1, stream);
+        }
+    }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = d->A; a.B = d->B; a.C = d->C;

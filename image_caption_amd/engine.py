@@ -465,7 +465,7 @@ class DecoderEngine:
                     ops.logits_ce_bwd_slab(h, W.head_w, W.head_b, labels, B, L, lse, gscale, v0, nv, dls, gb, bws)
             # the weight gradient first: nothing downstream waits for it but its all-reduce
             with self._span("head_wgrad_slab"):
-                ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True)
+                ops.gemm(dls, h, gW[v0:v0 + nv], M=nv, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws)
             if on_grad_ready is not None:
                 on_grad_ready(HEAD_W, v0, nv)
             # the slab's padding columns of dl are zero, and so are the rows that follow the vocabulary matrix

@@ -329,6 +329,25 @@ def test_gemm_split_k(gemm_mode, mode, M, N, K, out):
         close(acc, 2 * ref, 2e-3, "split-k accumulate")
 
 
+@pytest.mark.parametrize("akm", [True, False])
+def test_gemm_tail_split(akm):
+    """A plain deep-K product whose 256x256 tiles fill 2.3 rounds of the 256 CUs is cut into the whole rounds and a
+    split-K tail when a workspace is given (the vocabulary weight gradient: 50260 x 768 over 8192 rows): same result as
+    the single launch, rows on both sides of the cut compared with torch."""
+    M, N, K = 50260, 768, 4096
+    A = rnd(K, 50304, dtype=torch.bfloat16, seed=121)[:, :M] if akm else rnd(M, K, dtype=torch.bfloat16, seed=121)      # leading dimension 50304, as d(logits)
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.05, seed=122)
+    ws = torch.empty(8 * 8192 * N * 4, dtype=torch.uint8, device=DEV)
+    one = torch.full((M, N), float("nan"), device=DEV)
+    two = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, B, one, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=True)
+    ops.gemm(A, B, two, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=True, workspace=ws)
+    close(two, one, 1e-3, "tail split vs single launch")
+    rows = torch.cat([torch.arange(0, 512), torch.arange(43000, 44032), torch.arange(M - 300, M)]).to(DEV)
+    Ar = (A.t() if akm else A)[rows].float()
+    close(two[rows], Ar @ B.float(), 1.5e-2, "tail split vs torch")
+
+
 @pytest.mark.parametrize("mode", [0, 4, 6, 7])
 def test_head_dgrad_shape_split_k(gemm_mode, mode):
     """The data gradient of the vocabulary projection as the engine launches it: 8192 x 768 over a reduction of 50304
