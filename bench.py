@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--spinup-steps", type=int, default=150, help="untimed steps before the warm-up (device clocks / runtime pools settle)")
     ap.add_argument("--no-fold-norm1", action="store_true", help="block 0's norm1 applied as written (A/B of folding its affine into in_proj)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
     ap.add_argument("--no-scaled", action="store_true", help="skip the 12-block / 257-patch leg")
     ap.add_argument("--no-global-2048", action="store_true", help="skip the fixed-global-batch-2048 leg")
@@ -189,6 +190,7 @@ def pmc_traffic(span, args, B, whole_vocab):
     return None
 
 
+HEAD_SPANS = ("logits_ce_fwd", "ce_grad_from_probs", "logits_ce_bwd_slab", "head_wgrad_slab", "head_dgrad_slab")
 KERNEL_NAMES = {"logits_ce_fwd_kernel": "head_fwd_kernel<2,4,8,4,true,false> (persistent fused logits+CE forward, 256x256 tiles; bracketed alone)",
                 "logits_ce_fwd": "capdec_logits_ce_fwd as a whole: head_fwd_kernel + ce_finalize_kernel + ce_reduce_kernel",
                 "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,2,8,3> (EPI_CE_BWD, 256x128 tiles) + colpart_reduce_kernel",
@@ -291,7 +293,7 @@ def main():
         model.train()                                                   # decoder.py:144: dropout active
         return model, CaptionTrainer(model, lr=1e-4, weight_decay=0.01, bucket_bytes=args.bucket_mb << 20)
 
-    def timed(model, trainer, B, patches, steps, warmup, spinup, spans_wanted=True):
+    def timed(model, trainer, B, patches, steps, warmup, spinup, spans_wanted=True, stage_steps=5):
         """spinup + warmup untimed steps, then `steps` steps between two barriers; the MAX over ranks of the elapsed
         time.  Returns (seconds, last step's outputs, event-bracket summary)."""
         batch = make_batch(B, P=patches, L=32, d=768, vocab_size=50260, seed=42 + rank, device=dev)
@@ -302,7 +304,9 @@ def main():
         sync()
         for _ in range(warmup):
             trainer.step(inputs, labels, global_batch=B * world)
-        timer = KernelTimer()
+        # inside the timed steps only the vocabulary stage's launches are bracketed (5 event pairs per step); the per-stage
+        # breakdown of the blocks comes from separate, untimed steps: bracketing every stage costs 0.13 ms of a 3.7 ms step
+        timer = KernelTimer(only=HEAD_SPANS)
         if spans_wanted:
             model.engine.timer = timer
             head_kernel_timing(True)
@@ -321,6 +325,16 @@ def main():
         spans = timer.summary()
         if hk is not None:
             spans["logits_ce_fwd_kernel"] = hk
+        if spans_wanted and stage_steps > 0:
+            full = KernelTimer()
+            model.engine.timer = full
+            for _ in range(stage_steps):
+                trainer.step(inputs, labels, global_batch=B * world)
+            sync()
+            model.engine.timer = None
+            for name, rec in full.summary().items():
+                if name not in spans:
+                    spans[name] = (rec[0] * steps // stage_steps, rec[1])        # scaled to the timed steps' launch count
         return elapsed, out, spans
 
     if args.scaled_only:
@@ -335,7 +349,7 @@ def main():
     # two 20-35 ms stalls (tools/warmup_probe.py shows them: clock / power-state changes or runtime housekeeping, at a
     # different step from run to run), which a short warm-up leaves inside the timed steps.  A fixed number of steps, so
     # that every rank issues the same collectives.
-    elapsed, out, spans = timed(model, trainer, B, args.patches, args.steps, args.warmup, args.spinup_steps)
+    elapsed, out, spans = timed(model, trainer, B, args.patches, args.steps, args.warmup, args.spinup_steps, spans_wanted=not args.no_spans)
     loss = out[0].item() / out[2]
     slab = model.engine.last_slab
 

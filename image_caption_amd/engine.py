@@ -138,11 +138,17 @@ class KernelTimer:
     are launched on (torch's current stream), so per-launch device time can be read
     after the fact without synchronising inside the step."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: names to bracket (None: all).  An event pair costs the stream a few microseconds, so a timed run
+        brackets only what it reports from that run."""
         self.spans: Dict[str, list] = {}
+        self.only = None if only is None else frozenset(only)
 
     @contextlib.contextmanager
     def span(self, name: str):
+        if self.only is not None and name not in self.only:
+            yield
+            return
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         yield
