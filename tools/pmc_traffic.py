@@ -18,7 +18,8 @@ import sys
 LAUNCHES = {
     "logits_ce_fwd": ("head_fwd_kernel<2, 4, 8, 4, true, false, 0>", None),
     "logits_ce_bwd_slab": ("gemm_bf16_dma_kernel<false, false, 2, 2, 2, 8, 3>", None),
-    "head_wgrad_slab": ("gemm_bf16_pipe_kernel<true, true, 0, 8>", 197 * 3 * 256),
+    # two launches: the whole rounds of 256x256 tiles (170 x 3) and the split-K tail (27 x 3 tiles, 3 slabs)
+    "head_wgrad_slab": [("gemm_bf16_pipe_kernel<true, true, 0, 8>", 170 * 3 * 256), ("gemm_bf16_pipe_kernel<true, true, 0, 8>", 27 * 3 * 3 * 256)],
     "head_dgrad_slab": ("gemm_bf16_pipe_kernel<false, true, 0, 8>", 32 * 3 * 8 * 256),
 }
 
@@ -39,10 +40,12 @@ def pick(agg, pattern, grid):
 def main():
     fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
     res = {}
-    for span, (pattern, grid) in LAUNCHES.items():
-        f, w = pick(fetch, pattern, grid), pick(write, pattern, grid)
-        if f is None or w is None:
+    for span, parts in LAUNCHES.items():
+        parts = parts if isinstance(parts, list) else [parts]
+        fs, wr = [pick(fetch, pt, g) for pt, g in parts], [pick(write, pt, g) for pt, g in parts]
+        if any(v is None for v in fs + wr):
             continue
+        f, w = sum(fs), sum(wr)
         res[span] = {"fetch_size_kib": round(f), "write_size_kib": round(w),
                      "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024)}
     doc = {"collected_on": {"per_gpu_batch": 256, "dtype": "bf16", "n_blocks": 1, "patches": 196, "vocab_slab": "whole vocabulary"},
