@@ -119,6 +119,9 @@ SIGNATURES = {
     "capdec_ln_bwd_workspace": (c_long, [c_long, c_int]),
     "capdec_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "capdec_ln_bwd_dropout_workspace": (c_long, [c_long, c_int]),
+    "capdec_ln_bwd_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, Dropout, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_concat_ln_bwd_affine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "capdec_gemm_bias_act": (c_int, [C.POINTER(GemmDesc), c_void_p]),

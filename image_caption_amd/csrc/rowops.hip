@@ -3,6 +3,7 @@
 // One wave per row for the LayerNorm family (a 768-wide f32 row is 3 KiB =
 // 3 x 16 B per lane), 16-B vector accesses everywhere.
 #include <stdarg.h>
+#include <type_traits>
 #include "common.h"
 
 // ------------------------------------------------------------------ error text
@@ -119,17 +120,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
 // x comes either from a [M,d] f32 buffer or (CONCAT) straight from the three tensors the forward
 // joined, so the joined rows need not be kept.  dx_out == NULL: only the affine gradients are wanted
 // (the first block's input is data), which drops the two row reductions and the row store.
-template <typename TDY, typename TIN, bool CONCAT, int NV>
+// TG != void: the rows of dx_out also leave as g = dx_out * keep/(1-p) in TG (the gradient entering the residual
+// branch below this LayerNorm, i.e. the backward of `x + dropout(y)` w.r.t. y), and the column sums of g (the bias
+// gradient of the Linear that produced y) are accumulated next to dgamma / dbeta as a third partial row.
+struct LnDropOut { uint32_t thr, k0, k1; float scale; void* g; };
+
+template <typename TDY, typename TIN, bool CONCAT, int NV, typename TG = void>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float* x, const TIN* img, long img_bs, long img_ss,
                                                       const TIN* sos, const TIN* cap,
                                                       const float* pos, int B, int P, int L, const float* gamma,
                                                       const float* mean, const float* rstd, long M, int d,
-                                                      const float* dx_in, float* dx_out, float* partial) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 2 * 64 * 4];   // [wave][dgamma|dbeta][lane][4], one 1024-column slab per pass
+                                                      const float* dx_in, float* dx_out, float* partial, LnDropOut dr) {
+    constexpr bool GOUT = !std::is_void<TG>::value;
+    constexpr int NR = GOUT ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float red[4 * NR * 64 * 4];   // [wave][dgamma|dbeta|dbias][lane][4], one 1024-column slab per pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 dg[NV], db[NV];
+    f32x4 dg[NV], db[NV], dc[GOUT ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0}; }
+    if constexpr (GOUT) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dc[i] = f32x4{0, 0, 0, 0};
+    }
     const long nwaves = (long)gridDim.x * 4;
     for (long r = (long)blockIdx.x * 4 + wave; r < M; r += nwaves) {
         const float mu = mean[r], rs = rstd[r];
@@ -179,6 +191,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
                     for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                     if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + r * d + c);
                     *reinterpret_cast<f32x4*>(dx_out + r * d + c) = o;
+                    if constexpr (GOUT) {
+                        if (dr.thr) {
+                            bool keep[4];
+                            dropout_keep4(dr.k0, dr.k1, (uint32_t)(r * d + c), dr.thr, keep);    // d % 4 == 0: one hash per 4 columns
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * dr.scale : 0.f;
+                        }
+                        store4<TG>((TG*)dr.g + r * d + c, o);
+                        dc[i] += o;
+                    }
                 }
             }
         }
@@ -188,60 +210,78 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* dy, const float*
     for (int i = 0; i < NV; ++i) {
         if (i * 256 >= d) break;
         __syncthreads();
-        *reinterpret_cast<f32x4*>(&red[((wave * 2 + 0) * 64 + lane) * 4]) = dg[i];
-        *reinterpret_cast<f32x4*>(&red[((wave * 2 + 1) * 64 + lane) * 4]) = db[i];
+        *reinterpret_cast<f32x4*>(&red[((wave * NR + 0) * 64 + lane) * 4]) = dg[i];
+        *reinterpret_cast<f32x4*>(&red[((wave * NR + 1) * 64 + lane) * 4]) = db[i];
+        if constexpr (GOUT) *reinterpret_cast<f32x4*>(&red[((wave * NR + 2) * 64 + lane) * 4]) = dc[i];
         __syncthreads();
-        if (wave < 2) {
+        if (wave < NR) {
             const int c = lane * 4 + i * 256;
             if (c < d) {
                 f32x4 s = f32x4{0, 0, 0, 0};
-                for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * 2 + wave) * 64 + lane) * 4]);
-                *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * 2 + wave) * d + c) = s;
+                for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * NR + wave) * 64 + lane) * 4]);
+                *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * NR + wave) * d + c) = s;
             }
         }
     }
 }
 
 // 64 columns per block; 16 row groups each sum a fixed interleaved subset of the
-// per-block partials, then a fixed-order fold: deterministic for a given grid.
-// gridDim.y > 1: block row y folds partial rows [y * chunk, (y + 1) * chunk) into row pair y of `dgamma`
-// (a [gridDim.y][2][d] array, dbeta unused), which a second launch folds to the end.
-__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* dgamma, float* dbeta, int chunk) {
-    __shared__ float sa[16][64], sb[16][64];
+// per-block partials, then a fixed-order fold: deterministic for a given grid.  A partial holds NR rows of d
+// (dgamma, dbeta and, with NR == 3, the bias sums).
+// gridDim.y > 1: block row y folds partials [y * chunk, (y + 1) * chunk) into partial y of `o0`
+// (a [gridDim.y][NR][d] array, o1 / o2 unused), which a second launch folds to the end.
+template <int NR>
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int chunk) {
+    __shared__ float sa[NR][16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     int k0 = 0, k1 = nblk;
+    float* out[3] = {o0, o1, o2};
     if (gridDim.y > 1) {
         k0 = blockIdx.y * chunk;
         k1 = min(nblk, k0 + chunk);
-        dbeta = dgamma + ((long)blockIdx.y * 2 + 1) * d;
-        dgamma = dgamma + ((long)blockIdx.y * 2) * d;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) out[j] = o0 + ((long)blockIdx.y * NR + j) * d;
     }
-    float a = 0.f, b = 0.f;
+    float a[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) a[j] = 0.f;
     if (c < d)
-        for (int k = k0 + ty; k < k1; k += 16) { a += partial[((long)k * 2) * d + c]; b += partial[((long)k * 2 + 1) * d + c]; }
-    sa[ty][tx] = a; sb[ty][tx] = b;
+        for (int k = k0 + ty; k < k1; k += 16) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) a[j] += partial[((long)k * NR + j) * d + c];
+        }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) sa[j][ty][tx] = a[j];
     __syncthreads();
     if (ty == 0 && c < d) {
-        float ra = 0.f, rb = 0.f;
-        for (int j = 0; j < 16; ++j) { ra += sa[j][tx]; rb += sb[j][tx]; }
-        dgamma[c] = ra; dbeta[c] = rb;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            float r = 0.f;
+            for (int t = 0; t < 16; ++t) r += sa[j][t][tx];
+            out[j][c] = r;
+        }
     }
 }
 
-// Folds nb partial row pairs into dgamma / dbeta.  Many pairs (the row-streaming backward writes one per workgroup)
-// are folded in two launches, the first spread over LN_FOLD_GROUPS times as many workgroups; `scratch` holds
-// LN_FOLD_GROUPS row pairs.
+// Folds nb partials into dgamma / dbeta (and dbias when given: then a partial has three rows).  Many partials (the
+// row-streaming backward writes one per workgroup) are folded in two launches, the first spread over LN_FOLD_GROUPS
+// times as many workgroups; `scratch` holds LN_FOLD_GROUPS partials.
 constexpr int LN_FOLD_GROUPS = 32;
-void launch_ln_finalize(const float* partial, int nb, int d, float* dgamma, float* dbeta, float* scratch, hipStream_t st) {
+template <int NR>
+void launch_ln_finalize_rows(const float* partial, int nb, int d, float* dgamma, float* dbeta, float* dbias, float* scratch, hipStream_t st) {
     const unsigned gx = (unsigned)((d + 63) / 64);
+    float* nf = nullptr;
     if (scratch && nb >= 8 * LN_FOLD_GROUPS) {
         const int chunk = (nb + LN_FOLD_GROUPS - 1) / LN_FOLD_GROUPS;
-        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx, LN_FOLD_GROUPS), dim3(1024), 0, st, partial, nb, d, scratch, (float*)nullptr, chunk);
-        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx), dim3(1024), 0, st, (const float*)scratch, LN_FOLD_GROUPS, d, dgamma, dbeta, 0);
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel<NR>, dim3(gx, LN_FOLD_GROUPS), dim3(1024), 0, st, partial, nb, d, scratch, nf, nf, chunk);
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel<NR>, dim3(gx), dim3(1024), 0, st, (const float*)scratch, LN_FOLD_GROUPS, d, dgamma, dbeta, dbias, 0);
     } else {
-        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(gx), dim3(1024), 0, st, partial, nb, d, dgamma, dbeta, 0);
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel<NR>, dim3(gx), dim3(1024), 0, st, partial, nb, d, dgamma, dbeta, dbias, 0);
     }
+}
+void launch_ln_finalize(const float* partial, int nb, int d, float* dgamma, float* dbeta, float* scratch, hipStream_t st) {
+    launch_ln_finalize_rows<2>(partial, nb, d, dgamma, dbeta, nullptr, scratch, st);
 }
 
 // Workgroups of a LayerNorm backward over M rows.  With dx the kernel is a read-modify-write stream whose rows each
@@ -556,12 +596,45 @@ extern "C" int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const
     const float* nf = nullptr;
 #define CAPDEC_LNB_PLAIN(TDY, NVV)                                                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, float, false, NVV>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0, \
-                       gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial)
+                       gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial, LnDropOut{})
     if (dy_dtype == CAPDEC_BF16) { if (d <= 1024) CAPDEC_LNB_PLAIN(bf16_t, 4); else CAPDEC_LNB_PLAIN(bf16_t, 8); }
     else { if (d <= 1024) CAPDEC_LNB_PLAIN(float, 4); else CAPDEC_LNB_PLAIN(float, 8); }
 #undef CAPDEC_LNB_PLAIN
     // the workspace (capdec_ln_bwd_workspace) holds the fold's scratch behind the largest grid's partials
     launch_ln_finalize((const float*)partial, nb, d, dgamma, dbeta, (float*)partial + (long)ln_bwd_blocks(M, true) * 2 * d, st);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" long capdec_ln_bwd_dropout_workspace(long M, int d) { return (long)(ln_bwd_blocks(M, true) + LN_FOLD_GROUPS) * 3 * d * 4; }
+
+extern "C" int capdec_ln_bwd_dropout(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                                     const float* mean, const float* rstd, long M, int d,
+                                     const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+                                     capdec_dropout drop, void* g, int g_dtype, float* gbias,
+                                     void* partial, void* stream) {
+    CAPDEC_CHECK(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && g && gbias && partial, "ln_bwd_dropout: null pointer");
+    CAPDEC_CHECK(d > 0 && (d % 4) == 0 && d <= LN_MAX_D, "ln_bwd_dropout: need d %% 4 == 0 and d <= %d (d=%d)", LN_MAX_D, d);
+    CAPDEC_CHECK(g_dtype == CAPDEC_BF16 || g_dtype == CAPDEC_F32, "ln_bwd_dropout: g must be bf16 or f32");
+    CAPDEC_CHECK(M * d < (1L << 32) || drop.p <= 0.f, "ln_bwd_dropout: dropout index space exceeds 2^32 elements");
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 0) { (void)hipMemsetAsync(gbias, 0, (size_t)d * 4, st); return CAPDEC_OK; }
+    LnDropOut dr;
+    dr.thr = drop.p > 0.f ? dropout_threshold(drop.p) : 0u;
+    dr.k0 = drop.key0; dr.k1 = drop.key1;
+    dr.scale = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    dr.g = g;
+    const int nb = ln_bwd_blocks(M, true);
+    const float* nf = nullptr;
+#define CAPDEC_LNB_DROP(TDY, NVV, TGG)                                                                                                 \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, float, false, NVV, TGG>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, x, nf, 0L, 0L, nf, nf, nf, 1, 0, 0, \
+                       gamma, mean, rstd, M, d, dx_in, dx_out, (float*)partial, dr)
+#define CAPDEC_LNB_DROP_G(TDY, NVV) do { if (g_dtype == CAPDEC_BF16) CAPDEC_LNB_DROP(TDY, NVV, bf16_t); else CAPDEC_LNB_DROP(TDY, NVV, float); } while (0)
+    if (dy_dtype == CAPDEC_BF16) { if (d <= 1024) CAPDEC_LNB_DROP_G(bf16_t, 4); else CAPDEC_LNB_DROP_G(bf16_t, 8); }
+    else { if (d <= 1024) CAPDEC_LNB_DROP_G(float, 4); else CAPDEC_LNB_DROP_G(float, 8); }
+#undef CAPDEC_LNB_DROP_G
+#undef CAPDEC_LNB_DROP
+    launch_ln_finalize_rows<3>((const float*)partial, nb, d, dgamma, dbeta, gbias, (float*)partial + (long)nb * 3 * d, st);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -579,7 +652,7 @@ int ln_bwd_affine_from_sources(const void* dy, int dy_dtype, const void* img, lo
     const int Lk = L >= 0 ? L : 0;
 #define CAPDEC_LNB2(TDY, TIN, NVV)                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TIN, true, NVV>), dim3(nb), dim3(256), 0, st, (const TDY*)dy, nf, (const TIN*)img, \
-                       img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, pos, B, P, Lk, gamma, mean, rstd, M, d, nf, nd, (float*)partial)
+                       img_bs, img_ss, (const TIN*)sos, (const TIN*)cap, pos, B, P, Lk, gamma, mean, rstd, M, d, nf, nd, (float*)partial, LnDropOut{})
 #define CAPDEC_LNB(TDY, TIN) do { if (d <= 1024) CAPDEC_LNB2(TDY, TIN, 4); else CAPDEC_LNB2(TDY, TIN, 8); } while (0)
     const bool db = dy_dtype == CAPDEC_BF16, ib = in_dtype == CAPDEC_BF16;
     if (db && ib) CAPDEC_LNB(bf16_t, bf16_t);

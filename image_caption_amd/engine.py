@@ -491,9 +491,10 @@ class DecoderEngine:
             dx = self.buf("dx_last", (rows, d), torch.float32, dev, zero=True)
             dx[rows - Mh:].copy_(dH)
         dx_input = None
+        g2_done = False
         for i in reversed(range(nb)):
             need_dx_in = i > 0 or need_input_grad
-            dx = self._block_bwd(i, W, grads, dx, B, S, dev, need_dx_in)
+            dx, g2_done = self._block_bwd(i, W, grads, dx, B, S, dev, need_dx_in, g2_done)
             if on_grad_ready is not None:
                 on_grad_ready(("block", i), 0, 0)
         if need_input_grad:
@@ -502,7 +503,9 @@ class DecoderEngine:
         return loss_sum, correct, Mh
 
     # ------------------------------------------------------------------ one block, backward
-    def _block_bwd(self, i, W, grads, dx_out, B, S, dev, need_dx_in):
+    def _block_bwd(self, i, W, grads, dx_out, B, S, dev, need_dx_in, g2_done=False):
+        """Returns (dx of the block's input or None, whether the block below already has its first gradient:
+        the LayerNorm backward that ends this block then also wrote g_res.{(i-1) % 2} and its linear2.bias gradient)."""
         geo, cdt = self.geo, self.cdt
         d, ff, H, hd = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd
         nbk = geo.n_blocks
@@ -516,9 +519,11 @@ class DecoderEngine:
         csws = self.buf("colsum_ws", (max(ops.colsum_workspace(M, 3 * d), ops.colsum_workspace(Mt, 3 * d)),), torch.uint8, dev)
         G("linear1.bias").zero_()            # summed by atomics in a GEMM epilogue; the other bias gradients are overwritten
         # ---- MLP
-        g2 = self.buf("g_res", (Mt, d), cdt, dev)
-        with self._span("block_rowops_bwd"):
-            ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
+        # two buffers in turn: the block above fills the next one while this block's side-stream products may still read theirs
+        g2 = self.buf(f"g_res.{i % 2}", (Mt, d), cdt, dev)
+        if not g2_done:
+            with self._span("block_rowops_bwd"):
+                ops.dropout_bwd_cast(dx_out, k_r2, g2, G("linear2.bias"), csws)
         self._on_side_stream(lambda: ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         gcws = self.buf("gate_colsum_ws", ((Mt + 63) // 64 * ff * 4,), torch.uint8, dev)     # one partial row of bias sums per 64 rows
@@ -534,13 +539,13 @@ class DecoderEngine:
         with self._span("block_mlp_dgrad"):
             ops.gemm(dz1, w["linear1.weight"], dh2, M=Mt, N=d, K=ff, b_kmajor=True)
         dx_mid = self.buf(f"dx_mid", (Mt, d), torch.float32, dev)
-        lnws = self.buf("ln_ws", (ops.ln_bwd_workspace(M, d),), torch.uint8, dev)
-        with self._span("block_ln_bwd"):
-            ops.ln_bwd(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"), lnws)
-        # ---- attention
+        lnws = self.buf("ln_ws", (max(ops.ln_bwd_workspace(M, d), ops.ln_bwd_dropout_workspace(M, d)),), torch.uint8, dev)
+        # ---- attention: the gradient entering out_proj (dropout backward of dx_mid, with out_proj's bias gradient)
+        # leaves the LayerNorm backward's pass over the rows
         g1 = self.buf("g_res1", (Mt, d), cdt, dev)        # not g2's buffer: a side-stream product may still read that
-        with self._span("block_rowops_bwd"):
-            ops.dropout_bwd_cast(dx_mid, k_r1, g1, G("self_attn.out_proj.bias"), csws)
+        with self._span("block_ln_bwd"):
+            ops.ln_bwd_dropout(dh2, sv["x_mid"], w["norm2.weight"], sv["mean2"], sv["rstd2"], dx_out, dx_mid, G("norm2.weight"), G("norm2.bias"),
+                               k_r1, g1, G("self_attn.out_proj.bias"), lnws)
         self._on_side_stream(lambda: ops.gemm(g1, sv["attn_o"][r0:], G("self_attn.out_proj.weight"), M=d, N=d, K=Mt, a_kmajor=True,
                                               b_kmajor=True, workspace=skws))
         dattn = self.buf("dattn", (M, d), cdt, dev)
@@ -576,7 +581,7 @@ class DecoderEngine:
             self._join_side_stream()
             fws = self.buf("ln_fold_ws", (ops.ln_fold_bwd_workspace(3 * d, d),), torch.uint8, dev)
             ops.ln_fold_bwd(gin_w, gin_b, in_w, w["norm1.weight"], w["norm1.bias"], G("norm1.weight"), G("norm1.bias"), fws)
-            return None
+            return None, False
         if not need_dx_in:
             # no gradient flows below this block: dh1 only feeds norm1's affine gradients, so it is kept in
             # the compute dtype, rows below / from r0 come from two products over disjoint rows, and the
@@ -598,12 +603,14 @@ class DecoderEngine:
                 ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], None, None,
                            G("norm1.weight"), G("norm1.bias"), lnws)
             self._join_side_stream()
-            return None
-        dh1 = self.buf("dh1", (M, d), torch.float32, dev)
+            return None, False
         with self._span("block_qkv_dgrad"):
             if q_start == 0:
+                # one product: like dh2 it reaches the LayerNorm backward in the compute dtype
+                dh1 = self.buf("dh1c", (M, d), cdt, dev)
                 ops.gemm(dqkv, in_w, dh1, M=M, N=d, K=3 * d, b_kmajor=True)
             else:
+                dh1 = self.buf("dh1", (M, d), torch.float32, dev)     # summed from two products over different row ranges
                 ops.gemm(dqkv[:, d:], in_w[d:], dh1, M=M, N=d, K=2 * d, b_kmajor=True)
                 ops.gemm(dqkv[r0:, :d], in_w[:d], dh1[r0:], M=Mt, N=d, K=d, b_kmajor=True, accumulate=True)
         if q_start == 0:
@@ -612,10 +619,17 @@ class DecoderEngine:
             dres = self.buf("dres", (M, d), torch.float32, dev, zero=True)
             dres[r0:].copy_(dx_mid)
         dx_in = self.buf(f"dx_in.{i % 2}", (M, d), torch.float32, dev)
+        # the block below starts from the dropout backward of dx_in over the same rows: take it from this pass
+        below = i > 0 and self.saved[i - 1]["q_start"] == 0
         with self._span("block_ln_bwd"):
-            ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
+            if below:
+                g_below = self.buf(f"g_res.{(i - 1) % 2}", (M, d), cdt, dev)
+                ops.ln_bwd_dropout(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"),
+                                   self.saved[i - 1]["keys"][3], g_below, grads[block_key(i - 1, "linear2.bias", nbk)], lnws)
+            else:
+                ops.ln_bwd(dh1, sv["x_in"], w["norm1.weight"], sv["mean1"], sv["rstd1"], dres, dx_in, G("norm1.weight"), G("norm1.bias"), lnws)
         self._join_side_stream()
-        return dx_in
+        return dx_in, below
 
     # ------------------------------------------------------------------ all-rows logits (the reference's forward)
     def forward_logits(self, W: _Weights, source, *, train: bool, step: int = 0, pos=None) -> torch.Tensor:

@@ -126,6 +126,22 @@ def ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx_out, dgamma, dbeta, partial):
                                     ptr(dx_in), ptr(dx_out), ptr(dgamma), ptr(dbeta), ptr(partial), _st()), "capdec_ln_bwd")
 
 
+def ln_bwd_dropout_workspace(M, d) -> int:
+    return _lib.load().capdec_ln_bwd_dropout_workspace(M, d)
+
+
+def ln_bwd_dropout(dy, x, gamma, mean, rstd, dx_in, dx_out, dgamma, dbeta, drop: Dropout, g, gbias, partial):
+    """ln_bwd plus, from the same pass, g = dropout-backward of dx_out in g's dtype and gbias = column sums of g."""
+    require_cuda(dy, x, gamma, mean, rstd, dx_out, dgamma, dbeta, g, gbias, partial)
+    M, d = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dx_out.is_contiguous() and g.is_contiguous()
+    assert g.shape == (M, d) and dx_out.shape == (M, d) and gbias.numel() == d and gbias.dtype == torch.float32
+    assert partial.numel() * partial.element_size() >= ln_bwd_dropout_workspace(M, d)
+    check(_lib.load().capdec_ln_bwd_dropout(ptr(dy), dtype_code(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), M, d,
+                                            ptr(dx_in), ptr(dx_out), ptr(dgamma), ptr(dbeta), drop, ptr(g), dtype_code(g), ptr(gbias),
+                                            ptr(partial), _st()), "capdec_ln_bwd_dropout")
+
+
 def concat_ln_bwd_affine(dy, img, sos, cap, gamma, mean, rstd, dgamma, dbeta, partial, pos=None):
     require_cuda(dy, img, sos, cap, pos, gamma, mean, rstd, dgamma, dbeta, partial)
     B, P, d = img.shape

@@ -90,6 +90,16 @@ int capdec_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
                   const float* mean, const float* rstd, long M, int d,
                   const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
                   void* partial, void* stream);
+/* capdec_ln_bwd and the capdec_dropout_bwd_cast of its dx_out in one pass over the rows (decoder.py:58 below the
+ * residual dropout of decoder.py:55, and decoder.py:53 below that of the previous block's decoder.py:63):
+ * dx_out as above (required); g[m,c] = dx_out[m,c] * keep / (1-p) in g_dtype, the dropout element index being
+ * m*d + c; gbias[c] = column sums of g (f32, OVERWRITTEN).  partial: capdec_ln_bwd_dropout_workspace(M,d) bytes. */
+long capdec_ln_bwd_dropout_workspace(long M, int d);
+int capdec_ln_bwd_dropout(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                          const float* mean, const float* rstd, long M, int d,
+                          const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+                          capdec_dropout drop, void* g, int g_dtype, float* gbias,
+                          void* partial, void* stream);
 /* LayerNorm-1's affine folded into the packed QKV projection that follows it (decoder.py:53-54:
  * self_attn(norm1(x)) = xhat (W*gamma)^T + (b + W beta), xhat = the normalised rows): Wf[j,:] = W[j,:]*gamma,
  * bf[j] = bias[j] + sum_c W[j,c] beta[c].  W [N,K] in w_dtype, Wf [N,K] in wf_dtype (an f32 W may fold straight into a

@@ -691,6 +691,49 @@ def test_logits_ce(dtype, tol, B, L, V, d):
     close(dW, Wr.grad, 2e-2 if dtype == torch.bfloat16 else 1e-4, "dW")
 
 
+@pytest.mark.parametrize("M,d", [(37, 64), (5000, 768), (40000, 768), (300, 2048)])
+@pytest.mark.parametrize("dyt,gt,p", [(torch.bfloat16, torch.bfloat16, 0.1), (torch.float32, torch.float32, 0.1),
+                                      (torch.bfloat16, torch.bfloat16, 0.0)])
+def test_ln_bwd_with_dropout_output(M, d, dyt, gt, p):
+    """The LayerNorm backward that also emits the dropout backward of its dx (decoder.py:58 under decoder.py:55) against
+    the two separate passes: rows bit-identical, column sums to rounding of a different summation order."""
+    x = rnd(M, d, seed=80)
+    gamma, beta = 1 + 0.1 * rnd(d, seed=81), 0.1 * rnd(d, seed=82)
+    y = torch.empty(M, d, device=DEV, dtype=dyt)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.ln_fwd(x, gamma, beta, y, mean, rstd)
+    dy = rnd(M, d, seed=83).to(dyt)
+    dx_in = rnd(M, d, seed=84)
+    drop = ops.dropout_keys(5, 1, 3, p=p)
+    # separate passes
+    dx0 = torch.empty_like(x)
+    dg0, db0 = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    ws = torch.empty(max(ops.ln_bwd_workspace(M, d), ops.ln_bwd_dropout_workspace(M, d)), dtype=torch.uint8, device=DEV)
+    ops.ln_bwd(dy, x, gamma, mean, rstd, dx_in, dx0, dg0, db0, ws)
+    g0 = torch.empty(M, d, device=DEV, dtype=gt)
+    gb0 = torch.empty(d, device=DEV)
+    ops.dropout_bwd_cast(dx0, drop, g0, gb0)
+    # one pass; outputs poisoned first
+    dx1 = torch.full_like(x, float("nan"))
+    dg1, db1, gb1 = (torch.full((d,), float("nan"), device=DEV) for _ in range(3))
+    g1 = torch.full((M, d), float("nan"), device=DEV).to(gt)
+    ops.ln_bwd_dropout(dy, x, gamma, mean, rstd, dx_in, dx1, dg1, db1, drop, g1, gb1, ws)
+    assert torch.equal(dx1, dx0) and torch.equal(g1, g0)
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0)          # same grid and fold order as the plain kernel
+    close(gb1, gb0, 1e-5, "bias gradient from the fused pass")
+    if p > 0:
+        assert int((g1 == 0).sum()) > 0.05 * M * d                  # the mask was applied
+    # no incoming dx, in place over a dx_in alias, and twice the same bits
+    dx2 = dx_in.clone()
+    gb2 = torch.empty(d, device=DEV)
+    g2 = torch.empty_like(g1)
+    ops.ln_bwd_dropout(dy, x, gamma, mean, rstd, dx2, dx2, dg1, db1, drop, g2, gb2, ws)
+    assert torch.equal(dx2, dx0) and torch.equal(g2, g0) and torch.equal(gb2, gb1)
+    ops.ln_bwd(dy, x, gamma, mean, rstd, None, dx0, dg0, db0, ws)
+    ops.ln_bwd_dropout(dy, x, gamma, mean, rstd, None, dx1, dg1, db1, drop, g1, gb1, ws)
+    assert torch.equal(dx1, dx0)
+
+
 @pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
 def test_seqfirst_strided_ln_fwd_bwd(in_dtype):
     """LayerNorm-1 straight off a strided dataset slice [:, i:j, :] (decoder.py:163)."""
