@@ -561,7 +561,20 @@ class DecoderEngine:
         # in_proj's bias gradient (column sums of dQKV, a pure read stream) goes with its weight gradient: nothing
         # downstream waits for it, and next to the dgrad product on the main stream it costs next to nothing
         csws_side = self.buf("colsum_ws_side", (csws.numel(),), torch.uint8, dev)
-        if q_start == 0:
+        split_streams = bool(sv.get("folded"))
+        if split_streams:
+            # nothing is left for the main stream but to wait for these gradients: it takes the column sums and the
+            # query rows' product (with a split-K workspace of its own) while the side stream runs the large product
+            if q_start == 0:
+                self._on_side_stream(lambda: ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
+                ops.colsum(dqkv, gin_b, csws)
+            else:
+                self._on_side_stream(lambda: ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
+                skws_q = self.buf("splitk_ws_q", (32 * d * d * 4,), torch.uint8, dev)
+                ops.colsum(dqkv[:, d:], gin_b[d:], csws)
+                ops.colsum(dqkv[r0:, :d], gin_b[:d], csws)
+                ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws_q)
+        elif q_start == 0:
             def in_proj_grads():
                 ops.colsum(dqkv, gin_b, csws_side)
                 ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
@@ -571,7 +584,8 @@ class DecoderEngine:
                 ops.colsum(dqkv[:, d:], gin_b[d:], csws_side)
                 ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
                 ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
-        self._on_side_stream(in_proj_grads)
+        if not split_streams:
+            self._on_side_stream(in_proj_grads)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it
         in_w = w["self_attn.in_proj_weight"]
         if sv.get("folded"):
