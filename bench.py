@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--all-rows", action="store_true", help="run every row through the last block (no scored-rows-only skip)")
     ap.add_argument("--spinup-steps", type=int, default=150, help="untimed steps before the warm-up (device clocks / runtime pools settle)")
     ap.add_argument("--no-fold-norm1", action="store_true", help="block 0's norm1 applied as written (A/B of folding its affine into in_proj)")
+    ap.add_argument("--no-ce-row-reference", action="store_true",
+                    help="softmax numerators kept per 64-column slot and turned into d(logits) by a pass of its own (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
@@ -190,9 +192,9 @@ def pmc_traffic(span, args, B, whole_vocab):
     return None
 
 
-HEAD_SPANS = ("logits_ce_fwd", "ce_grad_from_probs", "logits_ce_bwd_slab", "head_wgrad_slab", "head_dgrad_slab")
-KERNEL_NAMES = {"logits_ce_fwd_kernel": "head_fwd_kernel<2,4,8,4,true,false> (persistent fused logits+CE forward, 256x256 tiles; bracketed alone)",
-                "logits_ce_fwd": "capdec_logits_ce_fwd as a whole: head_fwd_kernel + ce_finalize_kernel + ce_reduce_kernel",
+HEAD_SPANS = ("logits_ce_fwd", "ce_grad_from_probs", "ce_bwd_prepare", "ce_bias_grad", "logits_ce_bwd_slab", "head_wgrad_slab", "head_dgrad_slab")
+KERNEL_NAMES = {"logits_ce_fwd_kernel": "head_fwd_kernel<2,4,8,4,true,false,3> (persistent fused logits+CE forward, 256x256 tiles, numerators against the label's logit; bracketed alone)",
+                "logits_ce_fwd": "capdec_logits_ce_fwd_ref as a whole: label_logit_kernel + head_fwd_kernel + ce_finalize_kernel + ce_ref_fixup_kernel + ce_reduce_kernel",
                 "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,2,8,3> (EPI_CE_BWD, 256x128 tiles) + colpart_reduce_kernel",
                 "head_dgrad_slab": "gemm_bf16_pipe_kernel<false,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128, split-K) + splitk_reduce_kernel",
                 "head_wgrad_slab": "gemm_bf16_pipe_kernel<true,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128)"}
@@ -229,6 +231,11 @@ def head_roofline(spans, steps, B, slab, dtype):
     for name, (count, ms) in spans.items():
         if ms <= 0:
             continue
+        if name == "ce_bias_grad":
+            nbytes = 1.0 * Mh * V * esz
+            hbm_kernels[name] = {"launches_per_step": count // max(1, steps), "ms_per_launch": round(ms, 4),
+                                 "algorithmic_gb": round(nbytes / 1e9, 3), "gb_per_s": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_8tb_s": round(nbytes / (ms * 1e-3) / 8e12, 3)}
         if name == "ce_grad_from_probs":
             # HBM-bound pass: numerators read and d(logits) written in place, plus the forward's per-slot partials
             nbytes = 2.0 * Mh * Vp * esz + 16.0 * Mh * 2 * ((V + 127) // 128)
@@ -286,6 +293,8 @@ def main():
                              scored_rows_only=not args.all_rows, fold_norm1=not args.no_fold_norm1)
         if args.vocab_slab:
             opts.vocab_slab = args.vocab_slab
+        if args.no_ce_row_reference:
+            opts.ce_row_reference = False
         if args.no_wgrad_stream:
             opts.wgrad_stream = False
         torch.manual_seed(42)                                           # config.py:27,41

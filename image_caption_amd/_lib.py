@@ -49,6 +49,7 @@ class GemmDesc(C.Structure):
         ("kv_cache", c_void_p), ("kv_q", c_int), ("kv_d", c_int), ("kv_B", c_int), ("kv_H", c_int), ("kv_hd", c_int),
         ("kv_smax", c_int), ("kv_s0", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_long),
+        ("row_scale", c_void_p),
     ]
 
 
@@ -138,6 +139,12 @@ SIGNATURES = {
                                           c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int,
                                           c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_workspace": (c_long, [c_long, c_int]),
+    "capdec_logits_ce_fwd_ref": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
+                                         c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
+    "capdec_logits_ce_bwd_ref_prepare": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int,
+                                                 c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p]),
+    "capdec_colsum_weighted": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),

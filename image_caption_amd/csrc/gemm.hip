@@ -1454,15 +1454,27 @@ __device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2
         t.m2 = fmaxf(t.m2, pm);
     }
 }
+__device__ __forceinline__ void fold_push_ref(RowFold& t, float pm, int pa, float p2, float ps) {
+    if (pm > t.m1 || (pm == t.m1 && pa < t.a1)) { t.m2 = fmaxf(t.m1, p2); t.m1 = pm; t.a1 = pa; }
+    else t.m2 = fmaxf(t.m2, pm);
+    t.s += ps;
+}
 constexpr int FIN_ROWS = 32, FIN_GROUPS = 32;
 // dot = NULL: the label's logit comes from zlabel[] (written by the forward epilogue).  Otherwise it is formed here,
 // z[m, label] = h[m, :] . W[label, :] + bias[label] (bf16 operands, f32 sum in a fixed order): thread (row, group)
 // takes every 32nd 16-byte chunk of the two rows.
 struct LabelDot { const bf16_t* h; const bf16_t* W; const float* bias; long ldh, ldw; int d; };
+// REF: the partials were taken against a reference value per row, zlabel[m] = the label's logit (a value every row's
+// maximum is at least equal to): a slot holds {max (z - ref), sum exp(z - ref)}, the sums add up as they are, and
+// lse = ref + log(sum), row loss = log(sum).  rowflag[m] = 1 where the row's maximum lies so far above the reference
+// that numerators relative to it leave the range kept safe for the products of the backward (or the sum overflowed):
+// those rows are redone against their maximum by ce_ref_fixup_kernel.
+constexpr float CE_REF_LIMIT = 50.f;
+template <bool REF>
 __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, const float* zlabel, const int64_t* labels,
                                                            int ce_B, int ce_L, long M, int np,
                                                            float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
-                                                           float* rowloss, int32_t* rowcorrect, LabelDot dot) {
+                                                           float* rowloss, int32_t* rowcorrect, LabelDot dot, int32_t* rowflag) {
     __shared__ RowFold sh[FIN_GROUPS][FIN_ROWS];
     __shared__ float zdot[FIN_GROUPS][FIN_ROWS + 1];
     const int r = threadIdx.x & (FIN_ROWS - 1), w = threadIdx.x / FIN_ROWS;
@@ -1493,7 +1505,10 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
                 if (sl + u * FIN_GROUPS < np) q[u] = part4[(long)(sl + u * FIN_GROUPS) * M + m];
 #pragma unroll
             for (int u = 0; u < FIN_UNROLL; ++u)
-                if (sl + u * FIN_GROUPS < np) fold_push(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
+                if (sl + u * FIN_GROUPS < np) {
+                    if constexpr (REF) fold_push_ref(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
+                    else fold_push(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
+                }
         }
     }
     sh[w][r] = t;
@@ -1502,9 +1517,11 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
 #pragma unroll 1
         for (int i = 1; i < FIN_GROUPS; ++i) {
             const RowFold o = sh[i][r];
-            fold_push(t, o.m1, o.a1, o.m2, o.s);
+            if constexpr (REF) fold_push_ref(t, o.m1, o.a1, o.m2, o.s);
+            else fold_push(t, o.m1, o.a1, o.m2, o.s);
         }
-        const float lse = t.m1 + logf(t.s);
+        const float lse = REF ? zlabel[m] + logf(t.s) : t.m1 + logf(t.s);
+        if constexpr (REF) rowflag[m] = (t.m1 > CE_REF_LIMIT || !(t.s < 3.0e38f)) ? 1 : 0;
         if (lse_out) lse_out[m] = lse;
         if (argmax_out) argmax_out[m] = t.a1;
         if (ids_out) ids_out[m] = t.a1;
@@ -1520,7 +1537,7 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
             } else {
                 zl = zlabel[m];
             }
-            rowloss[m] = lse - zl;
+            rowloss[m] = REF ? logf(t.s) : lse - zl;
             rowcorrect[m] = ((long)t.a1 == lab) ? 1 : 0;
         }
     }
@@ -1542,6 +1559,108 @@ __global__ void ce_reduce_kernel(const float* rowloss, const int32_t* rowcorrect
         float r = 0.f; int rc = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { r += sf[i]; rc += si[i]; }
         loss_sum[0] = r; correct[0] = rc;
+    }
+}
+
+// ---- cross-entropy against a per-row reference (the label's logit): kernels around the persistent forward
+// z[m, label(m)] = h[m, :] . W[label, :] + bias[label], one wave per row (bf16 operands, f32 sum in a fixed order)
+__global__ __launch_bounds__(256) void label_logit_kernel(const bf16_t* h, long ldh, const bf16_t* W, long ldw, const float* bias, int d,
+                                                           const int64_t* labels, int ce_B, int ce_L, long M, float* out) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const long l = m / ce_B, b = m - l * ce_B;
+    const long lab = labels[b * ce_L + l];
+    const bf16_t* hr = h + m * ldh;
+    const bf16_t* wr = W + lab * ldw;
+    float a = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(hr + c), y = *reinterpret_cast<const bf16x8*>(wr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf((float)x[e], (float)y[e], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[m] = a + (bias ? bias[lab] : 0.f);
+}
+
+// Rows the finalize pass flagged (numerators against the label's logit out of the safe range: a label the model gives
+// a probability below e^-50) are redone here against their own maximum, one workgroup per row and plain dot products:
+// slow, and expected to run for no row at all.  Rewrites the row of numerators, its reference, lse and loss.
+__global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowflag, const bf16_t* h, long ldh, const bf16_t* W, long ldw,
+                                                            const float* bias, int d, int V, bf16_t* probs, long ld,
+                                                            float* rowref, float* lse, float* rowloss) {
+    const long m = blockIdx.x;
+    if (!rowflag[m]) return;
+    __shared__ float sm[4], ss[4];
+    const bf16_t* hr = h + m * ldh;
+    auto logit = [&](int v) {
+        const bf16_t* wr = W + (long)v * ldw;
+        float a = 0.f;
+        for (int c = 0; c < d; c += 8) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(hr + c), y = *reinterpret_cast<const bf16x8*>(wr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf((float)x[e], (float)y[e], a);
+        }
+        return a + (bias ? bias[v] : 0.f);
+    };
+    const float zl = rowref[m];
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, logit(v));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float sum = 0.f;
+    for (int v = threadIdx.x; v < ld; v += 256) {
+        const float e = v < V ? __expf(logit(v) - mx) : 0.f;
+        sum += e;
+        probs[m * ld + v] = (bf16_t)e;
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = mx + logf((ss[0] + ss[1]) + (ss[2] + ss[3]));
+        lse[m] = l; rowloss[m] = l - zl; rowref[m] = mx;
+    }
+}
+
+// What the backward products need besides the numerators e[m, v] = exp(z - ref_m):  with g_m = gscale * exp(ref_m - lse_m),
+//   d(logits)[m, v] = g_m * e'[m, v],   e' = e except e'[m, label] = e[m, label] - exp(lse_m - ref_m).
+// One wave per row: patches the label's numerator, writes rowscale[m] = g_m and hs[m, :] = g_m * h[m, :] (the weight
+// gradient's second operand; the data gradient applies g_m to its rows instead).
+__global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, long ld, const bf16_t* h, long ldh, int d,
+                                                                  const int64_t* labels, int ce_B, int ce_L, long M,
+                                                                  const float* lse, const float* rowref, float gscale,
+                                                                  bf16_t* hs, long ldhs, float* rowscale) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float e = rowref[m] - lse[m];
+    const float g = gscale * __expf(e);
+    for (int c = lane * 8; c < d; c += 512) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(h + m * ldh + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (bf16_t)(g * (float)x[k]);
+        *reinterpret_cast<bf16x8*>(hs + m * ldhs + c) = o;
+    }
+    if (lane == 0) {
+        rowscale[m] = g;
+        const long l = m / ce_B, b = m - l * ce_B;
+        bf16_t* pl = probs + m * ld + labels[b * ce_L + l];
+        *pl = (bf16_t)((float)*pl - __expf(-e));
+    }
+}
+
+// x[m, :] *= s[m]
+template <typename T>
+__global__ void scale_rows_kernel(T* x, long ldx, long M, int N, const float* s) {
+    const long total = M * N, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long m = i / N, n = i - m * N;
+        x[m * ldx + n] = from_f32<T>(to_f32<T>(x[m * ldx + n]) * s[m]);
     }
 }
 
@@ -1671,7 +1790,8 @@ __global__ __launch_bounds__(256) void ce_grad_from_probs_kernel(T* pd, long ld,
 
 // out = (accumulate ? out : 0) + sum over slabs, fixed order (deterministic)
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int split, long slab, int M, int N, T* out, long ldc, int accumulate,
+                                                            const float* row_scale) {
     // out[m, n] (+)= sum over the slabs, always in slab order; four columns per thread and the loads of four
     // slabs in flight at a time when the shapes allow 16-byte accesses
     const long stride = (long)gridDim.x * blockDim.x;
@@ -1691,6 +1811,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
                 a = (((a + v0) + v1) + v2) + v3;
             }
             for (; s2 < split; ++s2) a += *reinterpret_cast<const f32x4*>(ws + (long)s2 * slab + i);
+            if (row_scale) a *= row_scale[m];          // never together with accumulate (checked on the host)
             *reinterpret_cast<f32x4*>(dst) = a;
         }
         return;
@@ -1700,6 +1821,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
         const long m = i / N, n = i - m * N;
         float a = accumulate ? to_f32<T>(out[m * ldc + n]) : 0.f;
         for (int s2 = 0; s2 < split; ++s2) a += ws[s2 * slab + i];
+        if (row_scale) a *= row_scale[m];
         out[m * ldc + n] = from_f32<T>(a);
     }
 }
@@ -1732,7 +1854,29 @@ extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
 extern "C" void capdecdbg_gemm_extra_lds(int bytes) { g_extra_lds = bytes > 0 ? bytes : 0; }
 
 // ==================================================================== C ABI
+namespace { thread_local bool t_row_scaled = false; }      // the last product applied its row_scale on the way out
+static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream);
+
 extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
+    if (!d || !d->row_scale) return gemm_bias_act_impl(d, stream);
+    CAPDEC_CHECK(!d->accumulate && !d->bias && d->col_scale_n == 0 && d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual &&
+                 !d->gate && !d->aux_out && !d->colsum && !d->kv_cache, "gemm: row_scale goes with plain products only");
+    t_row_scaled = false;
+    const int rc = gemm_bias_act_impl(d, stream);
+    if (rc || t_row_scaled || d->M == 0 || d->N == 0) { t_row_scaled = true; return rc; }
+    // the kernel that ran has no row factor in its epilogue: one more pass over C
+    const long total = (long)d->M * d->N;
+    const int nb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (d->out_dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16_t*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
+    else
+        hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (float*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
+    CAPDEC_LAUNCH_CHECK();
+    t_row_scaled = true;
+    return CAPDEC_OK;
+}
+
+static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     CAPDEC_CHECK(d != nullptr, "gemm: null descriptor");
     CAPDEC_CHECK(d->M >= 0 && d->N >= 0 && d->K >= 0, "gemm: negative dimension");
     CAPDEC_CHECK(d->in_dtype == CAPDEC_BF16 || d->in_dtype == CAPDEC_F32, "gemm: bad in_dtype");
@@ -1760,6 +1904,7 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
             t1.M = d->M - (int)m0;
             t1.A = (const char*)d->A + (d->a_kmajor ? m0 : m0 * d->lda) * esz;
             t1.C = (char*)d->C + m0 * d->ldc * osz;
+            if (d->row_scale) t1.row_scale = d->row_scale + m0;
             int rc = capdec_gemm_bias_act(&h1, stream);
             if (rc) return rc;
             return capdec_gemm_bias_act(&t1, stream);
@@ -1828,10 +1973,11 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
             if (rc) return rc;
             const int nb = (int)((slab + 255) / 256 > 2048 ? 2048 : (slab + 255) / 256);
             if (a.out_dtype == CAPDEC_BF16)
-                hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (bf16_t*)a.C, a.ldc, a.accumulate);
+                hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (bf16_t*)a.C, a.ldc, a.accumulate, d->row_scale);
             else
-                hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (float*)a.C, a.ldc, a.accumulate);
+                hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (float*)a.C, a.ldc, a.accumulate, d->row_scale);
             CAPDEC_LAUNCH_CHECK();
+            if (d->row_scale) t_row_scaled = true;
             return CAPDEC_OK;
         }
     }
@@ -1893,17 +2039,17 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
 
 extern "C" long capdec_logits_ce_workspace(long M, int V) {
     const long np = 2L * ((V + BN - 1) / BN);
-    return (M * np * 4 + M * 3) * 4 + 256;
+    return (M * np * 4 + M * 4) * 4 + 256;
 }
 
 namespace {
-struct CeWs { f32x4* part4; float* zlabel; float* rowloss; int32_t* rowcorrect; int np; };
+struct CeWs { f32x4* part4; float* zlabel; float* rowloss; int32_t* rowcorrect; int32_t* rowflag; int np; };
 bool carve_ce_ws(void* ws, long bytes, long M, int V, CeWs& o) {
     if (!ws || bytes < capdec_logits_ce_workspace(M, V) || ((uintptr_t)ws & 15)) return false;
     o.np = 2 * ((V + BN - 1) / BN);
     const long n = M * o.np;
     o.part4 = (f32x4*)ws;
-    o.zlabel = (float*)ws + 4 * n; o.rowloss = o.zlabel + M; o.rowcorrect = (int32_t*)(o.rowloss + M);
+    o.zlabel = (float*)ws + 4 * n; o.rowloss = o.zlabel + M; o.rowcorrect = (int32_t*)(o.rowloss + M); o.rowflag = o.rowcorrect + M;
     return true;
 }
 void fill_head_args(GemmArgs& a, const void* h, const void* W, const float* bias, long M, int V, int d, long ldh, long ldw) {
@@ -1964,10 +2110,64 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
         rc = launch_gemm<EPI_CE_FWD>(a, dtype, st);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
+    hipLaunchKernelGGL(ce_finalize_kernel<false>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, labels, B, L, M, ws.np,
-                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, dot);
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, dot, (int32_t*)nullptr);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const float* bias, int dtype,
+                                        long M, int V, int d, long ldh, long ldw,
+                                        const int64_t* labels, int B, int L,
+                                        float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                                        void* probs, long ld_probs, float* rowref,
+                                        void* workspace, long workspace_bytes, void* stream) {
+    CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct && probs && rowref, "logits_ce_fwd_ref: null pointer");
+    CAPDEC_CHECK(dtype == CAPDEC_BF16, "logits_ce_fwd_ref: bf16 operands only");
+    CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd_ref: M (%ld) must equal B*L", M);
+    CAPDEC_CHECK(ld_probs >= V && (ld_probs % 8) == 0 && ld_probs <= (long)((V + BN - 1) / BN) * BN && aligned16(probs),
+                 "logits_ce_fwd_ref: ld_probs (%ld) must be a multiple of 8 in [V, roundup128(V)] and probs 16-byte aligned", ld_probs);
+    CAPDEC_CHECK(aligned16(rowref), "logits_ce_fwd_ref: rowref must be 16-byte aligned");
+    CeWs ws;
+    if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {
+        capdec_set_error("logits_ce_fwd_ref: workspace too small (%ld < %ld)", workspace_bytes, capdec_logits_ce_workspace(M, V));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    if (M == 0) return CAPDEC_OK;
+    HeadFwdArgs ha = {};
+    ha.A = (const bf16_t*)h; ha.B = (const bf16_t*)W; ha.bias = bias; ha.C = (bf16_t*)probs;
+    ha.lda = ldh; ha.ldb = ldw; ha.ldc = ld_probs; ha.M = (int)M; ha.N = V; ha.K = d; ha.store_cols = (int)ld_probs;
+    ha.part4 = ws.part4; ha.np = ws.np; ha.mode = 3; ha.rowref = rowref;
+    CAPDEC_CHECK(head_fwd_supported(ha), "logits_ce_fwd_ref: shape not supported (d %% 32 == 0, d >= 256, 16-byte aligned rows)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(label_logit_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)h, ldh, (const bf16_t*)W, ldw, bias, d,
+                       labels, B, L, M, rowref);
+    const int rc = head_fwd_launch(ha, g_gemm_mode == 8 ? 0 : g_head_fwd_geometry == 0 ? 0 : 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_finalize_kernel<true>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
+                       ws.part4, (const float*)rowref, labels, B, L, M, ws.np,
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, LabelDot{}, ws.rowflag);
+    hipLaunchKernelGGL(ce_ref_fixup_kernel, dim3((unsigned)M), dim3(256), 0, st, (const int32_t*)ws.rowflag, (const bf16_t*)h, ldh,
+                       (const bf16_t*)W, ldw, bias, d, V, (bf16_t*)probs, ld_probs, rowref, lse, ws.rowloss);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
+                                                const void* h, long ldh, int d,
+                                                const int64_t* labels, int B, int L,
+                                                const float* lse, const float* rowref, float gscale,
+                                                void* h_scaled, long ld_hs, float* rowscale, void* stream) {
+    CAPDEC_CHECK(probs && h && labels && lse && rowref && h_scaled && rowscale, "logits_ce_bwd_ref_prepare: null pointer");
+    CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_ref_prepare: M (%ld) must equal B*L", M);
+    CAPDEC_CHECK(ld_probs >= V && (d % 8) == 0 && (ldh % 8) == 0 && (ld_hs % 8) == 0 && ld_hs >= d && aligned16(h) && aligned16(h_scaled),
+                 "logits_ce_bwd_ref_prepare: rows of h / h_scaled must be 16-byte aligned, d a multiple of 8");
+    if (M == 0) return CAPDEC_OK;
+    hipLaunchKernelGGL(ce_ref_bwd_prepare_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)probs, ld_probs,
+                       (const bf16_t*)h, ldh, d, labels, B, L, M, lse, rowref, gscale, (bf16_t*)h_scaled, ld_hs, rowscale);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
@@ -1993,9 +2193,9 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     const int geo = margin ? -1 : head_fwd_choice(a, dtype, ha);      // the second maximum (margins) is the generic epilogue's
     const int rc = geo >= 0 ? head_fwd_launch(ha, geo, st) : launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
+    hipLaunchKernelGGL(ce_finalize_kernel<false>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
-                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr, LabelDot{});
+                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr, LabelDot{}, (int32_t*)nullptr);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

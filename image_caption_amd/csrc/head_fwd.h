@@ -1,6 +1,6 @@
 // Persistent bf16 product C = epilogue(A B^T + bias) with row-major operands: arguments and launcher.
 // mode 0: fused logits + cross-entropy forward; mode 1: bias / column scale / ReLU / dropout, bf16 output;
-// mode 2: residual + dropout(z + bias), f32 output.
+// mode 2: residual + dropout(z + bias), f32 output; mode 3: mode 0 against a caller-given reference value per row.
 #pragma once
 #include "common.h"
 
@@ -22,6 +22,9 @@ struct HeadFwdArgs {
     unsigned drop_thr, drop_k0, drop_k1; float drop_scale;      // thr 0: off; element index m * N + n
     // mode 2 (C is the f32 output [M, ldc], given through Cf; C itself unused): y = residual + dropout(z + bias)
     float* Cf; const float* residual; long ldr;
+    // mode 3: mode 0 with C required and everything taken against a given reference per row: the partials hold
+    // {max_n (z - rowref), sum_n exp(z - rowref), -inf, argmax}, C holds exp(z - rowref)
+    const float* rowref;
 };
 
 // geometry 0: 256x128 tiles, 4 waves, two workgroups per CU; 1: 256x256 tiles, 8 waves, one workgroup per CU

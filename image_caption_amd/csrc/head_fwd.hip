@@ -44,10 +44,12 @@ template <int WM, int WN, int TI, int NST> struct Geo {
     static constexpr int INFLIGHT = (NST - 2) * NP;      // DMA instructions that may stay outstanding at a step's wait
     static constexpr int RING = NST * STAGE;
     static constexpr int BIAS_BYTES = 1024;                // one DMA piece: up to 256 columns of f32 bias
-    static constexpr int LDS = RING + 2 * BIAS_BYTES;      // + the current and the next tile's bias slice
+    static constexpr int REF_BYTES = 1024;                 // one DMA piece: a tile's 256 rows of f32 row references
+    static constexpr int LDS = RING + 2 * BIAS_BYTES + 2 * REF_BYTES;      // + the current and the next tile's bias and row-reference slices
     static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024 && NW == 4) ? 2 : 1;
     static_assert(BNV * 4 <= BIAS_BYTES, "a tile's bias slice is one DMA piece");
     static_assert(NP <= TI, "one DMA piece per MFMA row at most");
+    static_assert(BMV * 4 <= REF_BYTES && NW >= 2, "a tile's row references are one DMA piece, fetched by wave 1");
 };
 
 struct View { const char* base; long rem; };     // an operand panel: first byte, bytes addressable from there
@@ -153,6 +155,13 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             dma_piece(rb, (unsigned)lane * 16u, smem + G::RING + sel * G::BIAS_BYTES);
         }
     };
+    // mode 3: the tile's slice of the row references -> LDS the same way (wave 1)
+    auto issue_ref = [&](int mm, int sel) {
+        if (MODE == 3 && wave == 1) {
+            const __amdgpu_buffer_rsrc_t rb = rsrc_at((const char*)(p.rowref + mm), (long)(p.M - mm) * 4);
+            dma_piece(rb, (unsigned)lane * 16u, smem + G::RING + 2 * G::BIAS_BYTES + sel * G::REF_BYTES);
+        }
+    };
     // column constants of a tile from that slice: the bias, PAST beyond N
     auto read_cb = [&](int nn, int sel, f32x4 (&cb)[4]) {
 #pragma unroll
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b = *reinterpret_cast<const f32x4*>(smem + G::RING + sel * G::BIAS_BYTES + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : (MODE != 0 ? 0.f : PAST);
+            for (int e = 0; e < 4; ++e) cb[j][e] = nn + c + e < p.N ? b[e] : ((MODE == 0 || MODE == 3) ? PAST : 0.f);
         }
     };
 
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
     if (STAMPS && tid == 0) t_start = __builtin_amdgcn_s_memtime();
     int bsel = 0;                                          // which of the two bias slices belongs to the current tile
     issue_bias(n0, 0);
+    issue_ref(m0, 0);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue_stage(va, vbv, s, s);
     // LDS-DMA loads and global stores of one wave do NOT complete in issue order relative to each other (a counted
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
 
     // one 32-deep step: wait for the stage, read its fragments, multiply, refill the slot read one step ago with
     // stage (rv, rk) -- of this tile or, in the last NST-1 steps, of the next one
-    auto step = [&](auto first, auto early, const View& rva, const View& rvb, int rk, int bias_nn) {
+    auto step = [&](auto first, auto early, const View& rva, const View& rvb, int rk, int bias_nn, int ref_mm) {
         // A tile's first NST-1 stages landed before the previous tile's epilogue stored anything (see there): no wait.
         // Later steps: all but the NST-2 youngest stages.  Stores may still be outstanding then; they only make this
         // wait stricter (loads complete in order among themselves), never laxer.
@@ -192,7 +202,15 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         __builtin_amdgcn_s_barrier();
         const char* st = smem + rslot * G::STAGE;
         f32x4 cb[4];
-        if constexpr (decltype(first)::value) read_cb(n0, bsel, cb);
+        float rr[MODE == 3 ? TI : 1];
+        if constexpr (decltype(first)::value) {
+            read_cb(n0, bsel, cb);
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    rr[i] = *reinterpret_cast<const float*>(smem + G::RING + 2 * G::BIAS_BYTES + bsel * G::REF_BYTES + (wr * G::WROWS + 16 * i + r16) * 4);
+            }
+        }
         bf16x8 af[TI], bfr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + fragB + j * 1024);
@@ -204,14 +222,17 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         const __amdgpu_buffer_rsrc_t rsb = rsrc_at(rvb.base + (long)rk * (DBK * 2), rvb.rem - (long)rk * (DBK * 2));
         rslot = rslot + 1 == NST ? 0 : rslot + 1;
         wslot = wslot + 1 == NST ? 0 : wslot + 1;
-        if (bias_nn >= 0) issue_bias(bias_nn, bsel ^ 1);       // ahead of this step's refill pieces: it lands before they do
+        if (bias_nn >= 0) { issue_bias(bias_nn, bsel ^ 1); issue_ref(ref_mm, bsel ^ 1); }       // ahead of this step's refill pieces: they land before those do
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // operands swapped: a lane then holds C[row = lane & 15][columns 4*(lane>>4) .. +3] of each 16x16 tile
-                if constexpr (decltype(first)::value) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], cb[j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (decltype(first)::value) {
+                    f32x4 c0 = cb[j];
+                    if constexpr (MODE == 3) c0 -= rr[i];          // the accumulators hold z - (the row's reference) from the start
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], c0, 0, 0, 0);
+                } else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
             if (i < G::NP) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -235,12 +256,12 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         unsigned long long t0 = 0;
         if (STAMPS && tid == 0) t0 = __builtin_amdgcn_s_memtime();
         // ---- the tile's k-steps: the first NST-1 find their stages landed, the last NST-1 refill from the next tile
-        step(T{}, T{}, va, vbv, NST - 1, -1);
+        step(T{}, T{}, va, vbv, NST - 1, -1, 0);
 #pragma unroll
-        for (int kt = 1; kt < NST - 1; ++kt) step(F{}, T{}, va, vbv, kt + NST - 1, -1);
-        for (int kt = NST - 1; kt < nk - (NST - 1); ++kt) step(F{}, F{}, va, vbv, kt + NST - 1, -1);
+        for (int kt = 1; kt < NST - 1; ++kt) step(F{}, T{}, va, vbv, kt + NST - 1, -1, 0);
+        for (int kt = NST - 1; kt < nk - (NST - 1); ++kt) step(F{}, F{}, va, vbv, kt + NST - 1, -1, 0);
 #pragma unroll
-        for (int s = 0; s < NST - 1; ++s) step(F{}, F{}, na, nbv, s, s == 0 ? nn : -1);
+        for (int s = 0; s < NST - 1; ++s) step(F{}, F{}, na, nbv, s, s == 0 ? nn : -1, mn);
         unsigned long long t1 = 0;
         if (STAMPS && tid == 0) { t1 = __builtin_amdgcn_s_memtime(); t_main += t1 - t0; }
 
@@ -324,7 +345,9 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     pm = t == 0 ? f : fmaxf(pm, f);
                 }
                 pm = quad_max(__uint_as_float(__float_as_uint(pm) | qbits));
-                const float nref = pm > -1.0e38f ? -pm * LOG2E : 0.f;      // a slot wholly past N: numerators exp2(-inf) = 0
+                // mode 3: the values are z - (row reference) already, and the numerators and their sum are taken against
+                // that reference, not the slot's maximum; else a slot wholly past N: numerators exp2(-inf) = 0
+                const float nref = MODE == 3 ? 0.f : (pm > -1.0e38f ? -pm * LOG2E : 0.f);
                 float sum = 0.f;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) { v[t] = __builtin_amdgcn_exp2f(fmaf(v[t], LOG2E, nref)); sum += v[t]; }
@@ -392,12 +415,13 @@ int launch_geo(const HeadFwdArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (nseen < 8) seen[nseen++] = (const void*)kfn;
         }
-        const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS && a.mode == 0 && a.C;      // the training forward only
+        const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS && (a.mode == 0 || a.mode == 3) && a.C;      // the training forward only
         if (timing) (void)hipEventRecord(g_timing.ev[2 * g_timing.n], st);
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * G::NW), G::LDS, st, a);
         if (timing) { (void)hipEventRecord(g_timing.ev[2 * g_timing.n + 1], st); ++g_timing.n; }
     };
-    if (a.mode == 2) go(head_fwd_kernel<WM, WN, TI, NST, false, false, 2>);
+    if (a.mode == 3) go(head_fwd_kernel<WM, WN, TI, NST, true, false, 3>);
+    else if (a.mode == 2) go(head_fwd_kernel<WM, WN, TI, NST, false, false, 2>);
     else if (a.mode == 1) go(head_fwd_kernel<WM, WN, TI, NST, true, false, 1>);
     else if (a.stamps) {                                  // diagnostic build of the same kernel: clock stamps per workgroup
         if (a.C) go(head_fwd_kernel<WM, WN, TI, NST, true, true>);
@@ -432,6 +456,7 @@ extern "C" int capdecdbg_head_fwd_timing_read(double* total_ms) {
 }
 
 bool head_fwd_supported(const HeadFwdArgs& a) {
+    if (a.mode == 3 && (!a.C || !a.rowref || !aligned16(a.rowref) || !a.part4)) return false;
     if (a.mode == 1 && (!a.C || (a.col_scale_n % 64) != 0 || (a.N % 8) != 0 || a.store_cols != a.N)) return false;
     if (a.mode == 2 && (a.C || !a.Cf || !a.residual || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ldr % 4) != 0 || !aligned16(a.Cf) ||
                         !aligned16(a.residual) || 256L * a.ldc * 4 >= 0x7FFFFFFFL || 256L * a.ldr * 4 >= 0x7FFFFFFFL)) return false;

@@ -316,7 +316,7 @@ __global__ void dropout_mask_kernel(uint32_t thr, uint32_t k0, uint32_t k1, long
 template <typename TI, typename TG, bool DROP>
 __global__ __launch_bounds__(256) void colsum_stripe_kernel(const TI* x, long M, int N, long ldx, int rows_per_stripe,
                                                              uint32_t thr, uint32_t k0, uint32_t k1, float scale,
-                                                             TG* g, float* partial) {
+                                                             TG* g, float* partial, const float* roww) {
     __shared__ __attribute__((aligned(16))) float red[4][64][4];
     const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 256 + cg * 4;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void colsum_stripe_kernel(const TI* x, long M,
             f32x4 v = f32x4{0, 0, 0, 0};
             if (full) v = load4<TI>(x + r * ldx + n);
             else for (int e = 0; e < 4 && n + e < N; ++e) v[e] = to_f32<TI>(x[r * ldx + n + e]);
+            if (roww) v *= roww[r];                                  // weighted column sums: sum_m w[m] x[m, n]
             if constexpr (DROP) {
                 if (thr) {
                     const uint32_t base = (uint32_t)(r * N + n);
@@ -376,6 +377,48 @@ __global__ __launch_bounds__(1024) void stripe_fold_kernel(const float* partial,
 #pragma unroll
         for (int j = 0; j < 16; ++j) r += sh[j][tx];
         out[c] = r;
+    }
+}
+
+// Weighted column sums of a wide bf16 array whose rows are 16-byte aligned (the vocabulary bias gradient from kept softmax
+// numerators): stage 1 with 16-byte loads.  A block owns a stripe of rows x 512 columns; a thread owns 8 columns and
+// every 4th row of the stripe, 4 loads in flight; the 4 row lanes are folded through LDS.  Columns from N on (up to the
+// row stride) may be read but are never written.
+__global__ __launch_bounds__(256) void wcolsum_bf16_kernel(const bf16_t* x, long M, int N, long ldx, int rows_per_stripe,
+                                                            const float* roww, float* partial) {
+    __shared__ __attribute__((aligned(16))) float red[4][64][8];
+    const int lane = threadIdx.x & 63, rl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long r0 = (long)blockIdx.y * rows_per_stripe;
+    const long r1 = r0 + rows_per_stripe < M ? r0 + rows_per_stripe : M;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const long n = (long)blockIdx.x * 512 + lane * 8;
+    const bool in = n + 8 <= ldx && n < N;            // the whole 16-byte group lies inside the row
+    if (in) {
+        auto add = [&](const bf16x8& q, float w) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf((float)q[e], w, acc[e]);
+        };
+        long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const bf16x8 q0 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + r * ldx + n));
+            const bf16x8 q1 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (r + 4) * ldx + n));
+            const bf16x8 q2 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (r + 8) * ldx + n));
+            const bf16x8 q3 = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (r + 12) * ldx + n));
+            add(q0, roww[r]); add(q1, roww[r + 4]); add(q2, roww[r + 8]); add(q3, roww[r + 12]);
+        }
+        for (; r < r1; r += 4) add(__builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + r * ldx + n)), roww[r]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][lane][e] = acc[e];
+    __syncthreads();
+    if (rl == 0 && in) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = ((acc[e] + red[1][lane][e]) + red[2][lane][e]) + red[3][lane][e];
+            if (n + e < N) partial[(long)blockIdx.y * N + n + e] = t;
+        }
     }
 }
 
@@ -727,13 +770,36 @@ extern "C" int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dr
     dim3 grid((N + 255) / 256, (unsigned)nstripes), block(256);
     float* part = colsum ? (float*)workspace : nullptr;
     if (g_dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL((colsum_stripe_kernel<float, bf16_t, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (bf16_t*)g, part);
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, bf16_t, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (bf16_t*)g, part, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (float*)g, part);
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, true>), grid, block, 0, st, dx, M, N, (long)N, rows, thr, d.key0, d.key1, scale, (float*)g, part, (const float*)nullptr);
     if (colsum) hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)part, nstripes, N, colsum);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }
+
+namespace {
+int colsum_launch(const void* x, int dtype, long M, int N, long ldx, const float* roww, float* colsum, void* workspace, hipStream_t st) {
+    if (M == 0) { (void)hipMemsetAsync(colsum, 0, (size_t)N * 4, st); return CAPDEC_OK; }
+    const int rows = colsum_stripe_rows(M);
+    const int nstripes = (int)((M + rows - 1) / rows);
+    dim3 grid((N + 255) / 256, (unsigned)nstripes), block(256);
+    float* nog = nullptr;
+    if (dtype == CAPDEC_BF16 && roww && N >= 4096 && (ldx % 8) == 0 && ((uintptr_t)x & 15) == 0 && ((long)(N + 7) / 8 * 8 <= ldx)) {
+        hipLaunchKernelGGL(wcolsum_bf16_kernel, dim3((N + 511) / 512, (unsigned)nstripes), block, 0, st, (const bf16_t*)x, M, N, ldx, rows, roww, (float*)workspace);
+        hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)workspace, nstripes, N, colsum);
+        CAPDEC_LAUNCH_CHECK();
+        return CAPDEC_OK;
+    }
+    else if (dtype == CAPDEC_BF16)
+        hipLaunchKernelGGL((colsum_stripe_kernel<bf16_t, float, false>), grid, block, 0, st, (const bf16_t*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace, roww);
+    else
+        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, false>), grid, block, 0, st, (const float*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace, roww);
+    hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)workspace, nstripes, N, colsum);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+}  // namespace
 
 extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum,
                              void* workspace, long workspace_bytes, void* stream) {
@@ -742,19 +808,17 @@ extern "C" int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, 
         capdec_set_error("colsum: workspace too small (%ld < %ld)", workspace_bytes, capdec_colsum_workspace(M, N));
         return CAPDEC_ERR_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (M == 0) { (void)hipMemsetAsync(colsum, 0, (size_t)N * 4, st); return CAPDEC_OK; }
-    const int rows = colsum_stripe_rows(M);
-    const int nstripes = (int)((M + rows - 1) / rows);
-    dim3 grid((N + 255) / 256, (unsigned)nstripes), block(256);
-    float* nog = nullptr;
-    if (dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL((colsum_stripe_kernel<bf16_t, float, false>), grid, block, 0, st, (const bf16_t*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace);
-    else
-        hipLaunchKernelGGL((colsum_stripe_kernel<float, float, false>), grid, block, 0, st, (const float*)x, M, N, ldx, rows, 0u, 0u, 0u, 1.f, nog, (float*)workspace);
-    hipLaunchKernelGGL(stripe_fold_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)workspace, nstripes, N, colsum);
-    CAPDEC_LAUNCH_CHECK();
-    return CAPDEC_OK;
+    return colsum_launch(x, dtype, M, N, ldx, nullptr, colsum, workspace, (hipStream_t)stream);
+}
+
+extern "C" int capdec_colsum_weighted(const void* x, int dtype, long M, int N, long ldx, const float* row_weight, float* colsum,
+                                      void* workspace, long workspace_bytes, void* stream) {
+    CAPDEC_CHECK(x && colsum && row_weight && M >= 0 && N > 0 && ldx >= N, "colsum_weighted: bad arguments");
+    if (!workspace || workspace_bytes < capdec_colsum_workspace(M, N)) {
+        capdec_set_error("colsum_weighted: workspace too small (%ld < %ld)", workspace_bytes, capdec_colsum_workspace(M, N));
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    return colsum_launch(x, dtype, M, N, ldx, row_weight, colsum, workspace, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ column sums without a caller workspace

@@ -55,6 +55,8 @@ class EngineOptions:
     dl_budget_bytes: int = 16 << 30               # cap on the d(logits) slab buffer (the whole vocabulary fits up to batch 5000 per GPU)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
+    ce_row_reference: bool = True                 # ... kept against one reference per row (the label's logit), so that d(logits) is a
+                                                  # row factor times the numerators and the backward products read them as they are
     composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     fold_norm1: bool = True                       # training without input gradient: block 0's norm1 affine is folded into in_proj
@@ -450,16 +452,40 @@ class DecoderEngine:
         from_probs = want_grads and slab >= Vpad and self.opt.keep_softmax_numerators
         self.last_from_probs = from_probs
         dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev) if want_grads else None
+        by_row = from_probs and self.opt.ce_row_reference and cdt == torch.bfloat16 and d % 32 == 0 and d >= 256
+        self.last_by_row = by_row
         with self._span("logits_ce_fwd"):
-            ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, probs=dl if from_probs else None)
+            if by_row:
+                rowref = self.buf("ce_rowref", (Mh,), torch.float32, dev)
+                ops.logits_ce_fwd_ref(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, dl, rowref)
+            else:
+                ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, probs=dl if from_probs else None)
         if not want_grads:
             return loss_sum, correct, Mh
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
-        bws = self.buf("ce_bwd_ws", (ops.logits_ce_bwd_workspace(Mh, slab),), torch.uint8, dev)
+        bws = self.buf("ce_bwd_ws", (max(ops.logits_ce_bwd_workspace(Mh, slab), ops.colsum_workspace(Mh, V)),), torch.uint8, dev)
         hws = self.buf("head_splitk_ws", (8 * Mh * d * 4,), torch.uint8, dev)
         first = True
-        for v0 in range(0, V, slab):
+        if by_row:
+            # d(logits) = rowscale[m] * numerators (label column patched): no pass over the [Mh, V] array but the products'
+            # own reads and the weighted column sums for the bias
+            hs = self.buf("head_in_scaled", (Mh, d), cdt, dev)
+            rowscale = self.buf("ce_rowscale", (Mh,), torch.float32, dev)
+            with self._span("ce_bwd_prepare"):
+                ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B, L, lse, rowref, gscale, hs, rowscale)
+            # on this stream: the products' workgroups take a CU's whole register file, so a pass running beside them
+            # only takes CUs away from them (on a second stream it cost the weight gradient twice its own duration)
+            with self._span("ce_bias_grad"):
+                ops.colsum_weighted(dl[:, :V], rowscale, gb, bws)
+            with self._span("head_wgrad_slab"):
+                ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws)
+            if on_grad_ready is not None:
+                on_grad_ready(HEAD_W, 0, V)
+            kk = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V
+            with self._span("head_dgrad_slab"):
+                ops.gemm(dl, W.head_w, dH, M=Mh, N=d, K=kk, b_kmajor=True, workspace=hws, row_scale=rowscale)
+        for v0 in (() if by_row else range(0, V, slab)):
             nv = min(slab, V - v0)
             ld = (nv + 127) // 128 * 128
             dls = dl if ld == dl.shape[1] else dl.view(-1)[:Mh * ld].view(Mh, ld)

@@ -160,10 +160,10 @@ def _ld(t: torch.Tensor) -> int:
 
 def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
          act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
-         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None):
+         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
     B is [N,K] (or [K,N] if b_kmajor)."""
-    require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache)
+    require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache, row_scale)
     assert A.dtype == B.dtype
     if M is None:
         M = A.shape[1] if a_kmajor else A.shape[0]
@@ -198,6 +198,9 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
     if workspace is not None:
         require_cuda(workspace)
         d.workspace, d.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.numel() == M and row_scale.is_contiguous()
+        d.row_scale = ptr(row_scale)
     check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
     return Cout
 
@@ -270,6 +273,33 @@ def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, work
                                            workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
 
 
+def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs, rowref):
+    """logits_ce_fwd with the numerators kept against one reference per row (rowref [M] f32, written here): probs [M, ld] bf16
+    = exp(z - rowref).  The backward starts from logits_ce_bwd_ref_prepare."""
+    require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace, probs, rowref)
+    M, d = h.shape
+    V = W.shape[0]
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    assert probs.dtype == h.dtype == torch.bfloat16 and probs.shape[0] == M
+    assert rowref.dtype == torch.float32 and rowref.numel() == M and rowref.is_contiguous()
+    check(_lib.load().capdec_logits_ce_fwd_ref(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
+                                               ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct),
+                                               ptr(probs), _ld(probs), ptr(rowref), ptr(workspace),
+                                               workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd_ref")
+
+
+def logits_ce_bwd_ref_prepare(probs, V, h, labels, B, L, lse, rowref, gscale, h_scaled, rowscale):
+    """In place: the label's numerator of every row is patched so that d(logits) = rowscale[m] * probs[m, :];
+    h_scaled = rowscale[:, None] * h (bf16), rowscale [M] f32."""
+    require_cuda(probs, h, labels, lse, rowref, h_scaled, rowscale)
+    M, d = h.shape
+    assert probs.shape[0] == M and h_scaled.shape == (M, d) and h_scaled.dtype == h.dtype == torch.bfloat16
+    assert rowscale.dtype == torch.float32 and rowscale.numel() == M
+    check(_lib.load().capdec_logits_ce_bwd_ref_prepare(ptr(probs), _ld(probs), M, V, ptr(h), _ld(h), d, ptr(labels), B, L,
+                                                       ptr(lse), ptr(rowref), gscale, ptr(h_scaled), _ld(h_scaled), ptr(rowscale), _st()),
+          "capdec_logits_ce_bwd_ref_prepare")
+
+
 def logits_ce_bwd_from_probs(probs_dl, V, labels, B, L, lse, gscale, fwd_workspace, dbias=None, workspace=None):
     """In place: softmax numerators -> (softmax - onehot) * gscale; dbias (optional) overwritten."""
     require_cuda(probs_dl, labels, lse, fwd_workspace, dbias, workspace)
@@ -338,6 +368,16 @@ def colsum(x, out, workspace=None):
     M, N = x.shape
     workspace, wsb = _colsum_ws(workspace, M, N, x.device)
     check(_lib.load().capdec_colsum(ptr(x), dtype_code(x), M, N, _ld(x), ptr(out), ptr(workspace), wsb, _st()), "capdec_colsum")
+
+
+def colsum_weighted(x, row_weight, out, workspace=None):
+    """out[n] = sum_m row_weight[m] * x[m, n] (overwritten, deterministic)."""
+    require_cuda(x, row_weight, out, workspace)
+    M, N = x.shape
+    assert row_weight.dtype == torch.float32 and row_weight.numel() == M
+    workspace, wsb = _colsum_ws(workspace, M, N, x.device)
+    check(_lib.load().capdec_colsum_weighted(ptr(x), dtype_code(x), M, N, _ld(x), ptr(row_weight), ptr(out), ptr(workspace), wsb, _st()),
+          "capdec_colsum_weighted")
 
 
 def embed_rows(table, ids, out, pos_row=None):

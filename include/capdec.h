@@ -163,6 +163,8 @@ typedef struct {
      * GPU is split along K into as many f32 slabs of M*N*4 bytes as pay off and fit (at most 32) and
      * summed in a fixed order */
     void* workspace; long workspace_bytes;
+    /* optional [M] f32: C = diag(row_scale) (A B); plain products only (no epilogue term, no accumulate) */
+    const float* row_scale;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);
@@ -255,6 +257,29 @@ int capdec_logits_ce_bwd_slab(const void* h, const void* W, const float* bias, i
                               int v0, int nv, void* dl, long ld_dl, float* dbias,
                               void* workspace, long workspace_bytes, void* stream);
 
+/* capdec_logits_ce_fwd (decoder.py:66 on the scored rows + decoder.py:172-183) with the softmax numerators kept
+ * against ONE reference value per row instead of one per 64-column slot: rowref[m] (out, [M] f32, 16-byte aligned) =
+ * the label's logit, probs[m,v] = exp(z[m,v] - rowref[m]) (bf16, required; columns V..ld_probs-1 zero).  d(logits) is
+ * then a row factor times the numerators (capdec_logits_ce_bwd_ref_prepare), so the backward products read probs as
+ * it is and no pass turns it into d(logits).  A row whose maximum exceeds its label's logit by more than 50 (label
+ * probability below e^-50) is redone against its maximum, rowref[m] holding that instead.  bf16 only, d % 32 == 0,
+ * d >= 256.  lse / argmax / loss_sum / correct / workspace as for capdec_logits_ce_fwd. */
+int capdec_logits_ce_fwd_ref(const void* h, const void* W, const float* bias, int dtype,
+                             long M, int V, int d, long ldh, long ldw,
+                             const int64_t* labels, int B, int L,
+                             float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
+                             void* probs, long ld_probs, float* rowref,
+                             void* workspace, long workspace_bytes, void* stream);
+/* Backward of decoder.py:172 from those numerators: with g[m] = gscale * exp(rowref[m] - lse[m]),
+ * d(logits)[m,v] = g[m] * probs'[m,v], probs' = probs except probs'[m,label] = probs[m,label] - exp(lse[m] - rowref[m])
+ * (patched IN PLACE here).  Writes rowscale[m] = g[m] ([M] f32) and h_scaled[m,:] = g[m] * h[m,:] (bf16 [M, ld_hs]):
+ *   d head.weight = probs'^T h_scaled,  d h = diag(rowscale) (probs' W)  (capdec_gemm_desc.row_scale),
+ *   d head.bias = capdec_colsum_weighted(probs', rowscale). */
+int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
+                                     const void* h, long ldh, int d,
+                                     const int64_t* labels, int B, int L,
+                                     const float* lse, const float* rowref, float gscale,
+                                     void* h_scaled, long ld_hs, float* rowscale, void* stream);
 /* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
  * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
 int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
@@ -277,6 +302,10 @@ int capdec_dropout_bwd_cast(const float* dx, long M, int N, capdec_dropout d,
 /* colsum[n] = sum_m x[m,n]  (bias gradients; OVERWRITTEN) */
 int capdec_colsum(const void* x, int dtype, long M, int N, long ldx, float* colsum,
                   void* workspace, long workspace_bytes, void* stream);
+/* colsum[n] = sum_m row_weight[m] * x[m,n]  (OVERWRITTEN; the vocabulary bias gradient of
+ * capdec_logits_ce_fwd_ref's numerators); workspace as for capdec_colsum. */
+int capdec_colsum_weighted(const void* x, int dtype, long M, int N, long ldx, const float* row_weight, float* colsum,
+                           void* workspace, long workspace_bytes, void* stream);
 /* capdec_colsum without a caller workspace.  No counterpart in the reference: it exists for callers that cannot
  * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
  * stripe partials go to a fixed CAPDEC_COLSUM_STATIC_BYTES array inside the library's code object (one copy per GPU,

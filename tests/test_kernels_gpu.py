@@ -248,6 +248,79 @@ def test_persistent_logits_ce_forward(gemm_mode, mode, B_, L, V, d, with_bias):
     assert int(ids.min()) >= 0 and int(ids.max()) < V
 
 
+@pytest.mark.parametrize("mode", [8, 9])
+@pytest.mark.parametrize("B_,L,V,d,with_bias,hot_rows", [
+    (5, 8, 1111, 256, True, 0),
+    (37, 9, 2000, 288, False, 0),
+    (1, 3, 130, 256, True, 0),
+    (64, 9, 50260, 768, True, 0),
+    (37, 9, 2000, 288, True, 7),         # rows whose label is (nearly) impossible: redone against their maximum
+])
+def test_logits_ce_row_reference(gemm_mode, mode, B_, L, V, d, with_bias, hot_rows):
+    """Forward with the numerators kept against one reference per row (the label's logit), and the backward built on it:
+    d(logits) = rowscale * numerators, the bias gradient as weighted column sums, both products -- against torch."""
+    M = B_ * L
+    h = rnd(M, d, dtype=torch.bfloat16, seed=171)
+    if hot_rows:
+        h[:hot_rows] *= 40.0                                                       # logits spread over +-100: label far below the maximum
+    w = rnd(V, d, dtype=torch.bfloat16, scale=2.0 / math.sqrt(d), seed=172)
+    b = rnd(V, seed=173) if with_bias else None
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(174)).to(DEV)
+    labels[0, 0], labels[-1, -1] = V - 1, 0
+    z = h.float() @ w.float().t() + (b if with_bias else 0.0)
+    lab_rows = labels.t().reshape(-1)
+    zl = z.gather(1, lab_rows[:, None])[:, 0]
+    ref_lse = torch.logsumexp(z, 1)
+    ref_loss = (ref_lse - zl).sum()
+    ref_dl = (torch.softmax(z, 1) - torch.nn.functional.one_hot(lab_rows, V)) / M
+    top2 = z.topk(2, -1)
+    decided = (top2.values[:, 0] - top2.values[:, 1]) > 0.05 * top2.values[:, 0].abs().clamp(min=1.0)
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    lse, amax = torch.full((M,), float("nan"), device=DEV), torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+    dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=torch.bfloat16)
+    rowref = torch.full((M,), float("nan"), device=DEV)
+    gemm_mode(mode)
+    ops.logits_ce_fwd_ref(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, dl, rowref)
+    gemm_mode(0)
+    close(lse, ref_lse, 2e-3, "lse")
+    assert abs(ls.item() - ref_loss.item()) <= 2e-3 * abs(ref_loss.item())
+    assert torch.equal(amax[decided].long(), top2.indices[decided, 0])
+    assert int(amax.min()) >= 0 and int(amax.max()) < V
+    assert cr.item() == int((amax.long() == lab_rows).sum())
+    far = (z.max(1).values - zl) > 50.0
+    assert int(far.sum()) >= hot_rows // 2 if hot_rows else int(far.sum()) == 0       # the hot rows (most of them) are out of range
+    want_ref = torch.where(far, z.max(1).values, zl)
+    ok_rows = ((z.max(1).values - zl) - 50.0).abs() > 1.0                         # not within rounding of the switch point
+    close(rowref[ok_rows], want_ref[ok_rows], 2e-3, "row reference")
+    assert not bool(torch.isnan(dl.float()).any()) and float(dl.float().min()) >= 0.0
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+    num = torch.exp(z - rowref[:, None])
+    rel = ((dl[:, :V].float() - num).abs() / (num + 1e-30)).max().item()
+    assert rel <= 2e-2, f"numerators: max relative error {rel:.3e}"
+    # backward pieces
+    hs = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    rowscale = torch.full((M,), float("nan"), device=DEV)
+    ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B_, L, lse, rowref, 1.0 / M, hs, rowscale)
+    close(rowscale[:, None] * dl[:, :V].float(), ref_dl, 1e-2, "d(logits) = rowscale * numerators")
+    close(hs, rowscale[:, None] * h.float(), 1e-2, "scaled head input")
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+    dbias = torch.full((V,), float("nan"), device=DEV)
+    ops.colsum_weighted(dl[:, :V], rowscale, dbias)
+    close(dbias, ref_dl.sum(0), 1e-2, "dbias")
+    gW = torch.full((V, d), float("nan"), device=DEV)
+    hws = torch.empty(8 * M * d * 4, dtype=torch.uint8, device=DEV)
+    ops.gemm(dl, hs, gW, M=V, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=hws)
+    close(gW, ref_dl.t() @ h.float(), 1e-2, "weight gradient")
+    wp = torch.zeros(Vp, d, device=DEV, dtype=torch.bfloat16)
+    wp[:V] = w
+    for use_ws in (True, False):                                                   # row factor in the split-K fold / as a pass of its own
+        dH = torch.full((M, d), float("nan"), device=DEV)
+        ops.gemm(dl, wp, dH, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws if use_ws else None, row_scale=rowscale)
+        close(dH, ref_dl @ w.float(), 1e-2, "data gradient")
+
+
 def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
     """200 launches of each geometry on one input give bit-identical numerators and partial sums: the operand ring's
     waits are sufficient on every tile of every launch (a stage read before it had landed shows up here)."""
