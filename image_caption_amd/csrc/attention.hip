@@ -226,6 +226,16 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     t[0] = (bf16_t)lo; t[1] = (bf16_t)hi;
     return __builtin_bit_cast(uint32_t, t);
 }
+// x, y: a lane's 4 columns (4g .. 4g+3) of two adjacent 16-column accumulator tiles, scaled and rounded to bf16; returns 8
+// consecutive columns of one of the tiles: lanes with even g get columns 4g .. 4g+7 of x's tile, odd g columns
+// 4(g-1) .. 4(g-1)+7 of y's tile.  Every lane of the wave must execute it.
+__device__ __forceinline__ u32x4 swap_pair(const f32x4& x, const f32x4& y, float scale) {
+    const uint32_t x0 = pack_bf16(x[0] * scale, x[1] * scale), x1 = pack_bf16(x[2] * scale, x[3] * scale);
+    const uint32_t y0 = pack_bf16(y[0] * scale, y[1] * scale), y1 = pack_bf16(y[2] * scale, y[3] * scale);
+    const u32pair s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+    const u32pair s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
 
 // the value quad lane R holds, in all four lanes of every aligned quad
 template <int R>
@@ -242,6 +252,15 @@ __device__ __forceinline__ int key_limit(int q, int S, int mask_mode, int open_c
 // SEQ = true (long query ranges): ONE workgroup of 8 waves owns the whole (sequence, head); K and V are both
 // staged in LDS once and every wave walks the query tiles wave, wave + 8, ...  K, V, Q and O then cross the
 // memory system once per head instead of once per 64-query slab (V) and once per wave (K).
+// Workgroup -> (sequence, head): consecutive workgroup ids go to the 8 XCDs in turn, each with an L2 of its own, and a
+// head's rows are 2*hd-byte pieces of rows that hold all heads (the packed QKV layout) -- pieces that share 128-byte
+// lines with the neighbouring heads'.  Each XCD therefore gets a contiguous run of (sequence, head) pairs: the heads
+// of a sequence are fetched through one L2 at about the same time, and a line is read from memory once.
+__device__ __forceinline__ int xcd_logical(int bid, int n) {
+    const int qq = n >> 3, r = n & 7, x = bid & 7;
+    return (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + (bid >> 3);
+}
+
 template <int HD, bool SEQ>
 __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,9 +276,10 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(At
         const int fb = hh / p.H, fh = hh - fb * p.H;
         pre.fetch((const bf16_t*)p.v + fb * p.v_bs + fh * p.v_hs, p.v_ss, (const bf16_t*)p.k + fb * p.k_bs + fh * p.k_hs, p.k_ss, 0, p.S, tid);
     };
-    if constexpr (SEQ) fetch_head(blockIdx.x);
-    // SEQ: persistent, the workgroup walks (sequence, head) pairs blockIdx.x, + gridDim.x, ...
-    for (int bh = blockIdx.x;; bh += gridDim.x) {
+    const int bh0 = xcd_logical(blockIdx.x, gridDim.x);
+    if constexpr (SEQ) fetch_head(bh0);
+    // SEQ: persistent, the workgroup walks (sequence, head) pairs bh0, + gridDim.x, ...
+    for (int bh = bh0;; bh += gridDim.x) {
     const int b = bh / p.H, h = bh - b * p.H;
     const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
     bf16x8 kf[4][G::KS];
@@ -417,7 +437,7 @@ template <int HD, bool SEQ>
 __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int bh = xcd_logical(blockIdx.x, gridDim.x), b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
     const int nthreads = blockDim.x;
@@ -546,7 +566,7 @@ template <int HD, bool SEQ>
 __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int bh = xcd_logical(blockIdx.x, gridDim.x), b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int nq = min(p.nq, p.S - p.q_start);
     const int NQP = (nq + 31) & ~31;
@@ -624,16 +644,19 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfm
             dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(Ql, q0, q0 + 16, dt * 16, lane), dsf, dkacc[dt], 0, 0, 0);
         }
     }
-    if (kok) {
+    {
         bf16_t* dkrow = (bf16_t*)p.dk + b * p.dk_bs + h * p.dk_hs + (long)key * p.dk_ss;
         bf16_t* dvrow = (bf16_t*)p.dv + b * p.dv_bs + h * p.dv_hs + (long)key * p.dv_ss;
+        const int colq = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) {
-            bf16x4 a, c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dkacc[dt][r]; c[r] = (bf16_t)(dvacc[dt][r] * p.drop_scale); }
-            *reinterpret_cast<bf16x4*>(dkrow + dt * 16 + 4 * g) = a;
-            *reinterpret_cast<bf16x4*>(dvrow + dt * 16 + 4 * g) = c;
+        for (int dt = 0; dt < G::DT; dt += 2) {
+            // a lane's 4 + 4 columns of two adjacent 16-column tiles become 8 consecutive columns of one of them
+            // (v_permlane16_swap per dword, every lane takes part): 16-byte stores, 64 contiguous bytes per row and instruction
+            const u32x4 dk8 = swap_pair(dkacc[dt], dkacc[dt + 1], 1.f), dv8 = swap_pair(dvacc[dt], dvacc[dt + 1], p.drop_scale);
+            if (kok) {
+                *reinterpret_cast<u32x4*>(dkrow + dt * 16 + colq) = dk8;
+                *reinterpret_cast<u32x4*>(dvrow + dt * 16 + colq) = dv8;
+            }
         }
     }
     }
@@ -967,7 +990,7 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
     if (d->fwd.dtype == CAPDEC_BF16) {
         CAPDEC_CHECK(strides_ok8(a.q_bs, a.q_hs, a.q_ss) && strides_ok8(a.k_bs, a.k_hs, a.k_ss) && strides_ok8(a.v_bs, a.v_hs, a.v_ss) &&
                      strides_ok8(a.do_bs, a.do_hs, a.do_ss) && (a.dq_bs % 4) == 0 && (a.dq_hs % 4) == 0 && (a.dq_ss % 4) == 0 &&
-                     (a.dk_bs % 4) == 0 && (a.dk_hs % 4) == 0 && (a.dk_ss % 4) == 0 && (a.dv_bs % 4) == 0 && (a.dv_hs % 4) == 0 && (a.dv_ss % 4) == 0 &&
+                     strides_ok8(a.dk_bs, a.dk_hs, a.dk_ss) && strides_ok8(a.dv_bs, a.dv_hs, a.dv_ss) &&
                      aligned16(a.dout) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv),
                      "attn_bwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
         const int SP = (a.S + 63) & ~63;

@@ -191,7 +191,7 @@ typedef struct {
 int capdec_attn_fwd(const capdec_attn_desc* desc, void* stream);
 
 /* Backward: given do (same addressing as o) produce dq, dk, dv (addressing given
- * by dq_*, dk_*, dv_* strides).  delta [B*H*S] f32 scratch (rowsum(do*o)).
+ * by dq_*, dk_*, dv_* strides; bf16: dk / dv strides multiples of 8 elements, 16-byte stores).  delta [B*H*S] f32 scratch (rowsum(do*o)).
  * Queries outside [q_start, q_start+nq) contribute nothing; dq rows outside are
  * not written. */
 typedef struct {
