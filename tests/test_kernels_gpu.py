@@ -345,6 +345,19 @@ def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
             bad += (dl.view(torch.int16) != first[0].view(torch.int16)).sum() + (lse != first[1]).sum() + (amax != first[2]).sum()
         gemm_mode(0)
         assert int(bad) == 0, f"mode {mode}: {int(bad)} elements differed between launches"
+    # the same with the numerators taken against the label's logit (the training default)
+    rowref = torch.empty(M, device=DEV)
+    for mode in (8, 9):
+        gemm_mode(mode)
+        ops.logits_ce_fwd_ref(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, dl, rowref)
+        first = (dl.clone(), lse.clone(), amax.clone(), rowref.clone())
+        bad = torch.zeros((), dtype=torch.int64, device=DEV)
+        for _ in range(200):
+            ops.logits_ce_fwd_ref(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, dl, rowref)
+            bad += ((dl.view(torch.int16) != first[0].view(torch.int16)).sum() + (lse != first[1]).sum() + (amax != first[2]).sum()
+                    + (rowref != first[3]).sum())
+        gemm_mode(0)
+        assert int(bad) == 0, f"row reference, mode {mode}: {int(bad)} elements differed between launches"
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 2e-5)])
