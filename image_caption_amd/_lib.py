@@ -78,6 +78,7 @@ class AttnBwdDesc(C.Structure):
         ("dv", c_void_p), ("dv_bs", c_long), ("dv_hs", c_long), ("dv_ss", c_long),
         ("dq_scale", c_float),
         ("delta", c_void_p),
+        ("colsum_q", c_void_p), ("colsum_kv", c_void_p),
     ]
 
 
@@ -128,6 +129,7 @@ SIGNATURES = {
     "capdec_gemm_bias_act": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "capdec_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "capdec_attn_bwd": (c_int, [C.POINTER(AttnBwdDesc), c_void_p]),
+    "capdec_attn_bwd_colsum_rows": (None, [c_int, c_int, c_int, c_int, C.POINTER(c_long), C.POINTER(c_long)]),
     "capdec_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "capdec_logits_ce_workspace": (c_long, [c_long, c_int]),
     "capdec_logits_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,

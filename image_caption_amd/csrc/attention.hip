@@ -30,6 +30,9 @@ struct AttnArgs {
     void* dk; long dk_bs, dk_hs, dk_ss;
     void* dv; long dv_bs, dv_hs, dv_ss;
     float dq_scale; float* delta;
+    // optional: column sums of dq and of dk | dv per 16-row tile t of a (sequence, head):
+    // colsum_q[(b * ntq + t) * H*hd + h*hd + c], colsum_kv[(b * ntk + t) * 2*H*hd + {0, H*hd} + h*hd + c]
+    float* colsum_q; float* colsum_kv; int ntq, ntk;
 };
 
 __device__ __forceinline__ bool key_visible(int q, int key, int S, int mask_mode, int open_cols) {
@@ -226,6 +229,33 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     t[0] = (bf16_t)lo; t[1] = (bf16_t)hi;
     return __builtin_bit_cast(uint32_t, t);
 }
+// Column sums over the 16 rows of a wave's accumulator tiles: lane (g, i) holds columns 16 dt + 4g .. + 3 of row i; after
+// the fold every lane holds the sums over i.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int DT>
+__device__ __forceinline__ void fold_rows16(f32x4 (&a)[DT]) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // data-parallel-primitive adds inside the row of 16 lanes: neighbours, quad halves, mirrored halves of 8, mirrored row
+            float v = a[dt][r];
+            v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
+            a[dt][r] = v;
+        }
+}
+// ... and leave as one row of partial sums: dst[16 dt + 4g .. + 3] = scale * sums (lanes with i == 0 write)
+template <int DT>
+__device__ __forceinline__ void write_colsums(const f32x4 (&a)[DT], float scale, int g, int i, float* dst) {
+    if (i == 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16 + 4 * g) = a[dt] * scale;
+    }
+}
+
 // x, y: a lane's 4 columns (4g .. 4g+3) of two adjacent 16-column accumulator tiles, scaled and rounded to bf16; returns 8
 // consecutive columns of one of the tiles: lanes with even g get columns 4g .. 4g+7 of x's tile, odd g columns
 // 4(g-1) .. 4(g-1)+7 of y's tile.  Every lane of the wave must execute it.
@@ -556,6 +586,12 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma
             *reinterpret_cast<bf16x4*>(dqrow + dt * 16 + 4 * g) = o;
         }
     }
+    if (p.colsum_q) {                                                // the tile's column sums (rows past the range hold zeros)
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) acc[dt] = qok ? acc[dt] : f32x4{0, 0, 0, 0};
+        fold_rows16<G::DT>(acc);
+        write_colsums<G::DT>(acc, p.dq_scale, g, i, p.colsum_q + ((long)b * p.ntq + ((qw - p.q_start) >> 4)) * ((long)p.H * HD) + h * HD);
+    }
     }
 }
 
@@ -657,6 +693,18 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfm
                 *reinterpret_cast<u32x4*>(dkrow + dt * 16 + colq) = dk8;
                 *reinterpret_cast<u32x4*>(dvrow + dt * 16 + colq) = dv8;
             }
+        }
+        if (p.colsum_kv) {                                           // the tile's column sums (keys past the sequence hold zeros)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                dkacc[dt] = kok ? dkacc[dt] : f32x4{0, 0, 0, 0};
+                dvacc[dt] = kok ? dvacc[dt] : f32x4{0, 0, 0, 0};
+            }
+            float* dst = p.colsum_kv + ((long)b * p.ntk + (kw >> 4)) * (2L * p.H * HD) + h * HD;
+            fold_rows16<G::DT>(dkacc);
+            write_colsums<G::DT>(dkacc, 1.f, g, i, dst);
+            fold_rows16<G::DT>(dvacc);
+            write_colsums<G::DT>(dvacc, p.drop_scale, g, i, dst + (long)p.H * HD);
         }
     }
     }
@@ -971,6 +1019,30 @@ extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
     return CAPDEC_OK;
 }
 
+namespace {
+// which kernels capdec_attn_bwd runs and their grids along the queries (dq kernel) / keys (dk/dv kernel) of a
+// (sequence, head); 16-row tiles per (sequence, head), each of which leaves one row of partial column sums
+struct BwdPlan { bool seq_q, seq_kv; int nwaves_q, nyq, nyk, ntq, ntk; };
+BwdPlan bwd_plan(int S, int nq, int hd) {
+    BwdPlan pl;
+    const int SP = (S + 63) & ~63;
+    const int lds_q = SP * (hd * 2 + 16);
+    pl.seq_q = nq > 64 && 2 * lds_q <= 160 * 1024;
+    pl.seq_kv = nq > 64 && S > 128;
+    pl.nwaves_q = nq >= 64 ? 4 : (nq + 15) / 16;
+    pl.nyq = pl.seq_q ? 1 : (nq > 0 ? (nq + 16 * pl.nwaves_q - 1) / (16 * pl.nwaves_q) : 0);
+    pl.nyk = pl.seq_kv ? 1 : (S + 63) / 64;
+    pl.ntq = (nq + 15) / 16; pl.ntk = (S + 15) / 16;               // 16-row tiles: one row of partial column sums each
+    return pl;
+}
+}  // namespace
+
+extern "C" void capdec_attn_bwd_colsum_rows(int B, int S, int nq, int hd, long* q_rows, long* kv_rows) {
+    const BwdPlan pl = bwd_plan(S, nq, hd);
+    if (q_rows) *q_rows = (long)B * pl.ntq;
+    if (kv_rows) *kv_rows = (long)B * pl.ntk;
+}
+
 extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
     CAPDEC_CHECK(d, "attn_bwd: null descriptor");
     AttnArgs a;
@@ -982,6 +1054,10 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
     a.dk = d->dk; a.dk_bs = d->dk_bs; a.dk_hs = d->dk_hs; a.dk_ss = d->dk_ss;
     a.dv = d->dv; a.dv_bs = d->dv_bs; a.dv_hs = d->dv_hs; a.dv_ss = d->dv_ss;
     a.dq_scale = d->dq_scale; a.delta = d->delta;
+    const BwdPlan pl = bwd_plan(a.S, a.nq, a.hd);
+    a.colsum_q = d->colsum_q; a.colsum_kv = d->colsum_kv; a.ntq = pl.ntq; a.ntk = pl.ntk;
+    CAPDEC_CHECK((!d->colsum_q && !d->colsum_kv) || d->fwd.dtype == CAPDEC_BF16, "attn_bwd: column sums come with the bf16 kernels only");
+    CAPDEC_CHECK((!d->colsum_q || aligned16(d->colsum_q)) && (!d->colsum_kv || aligned16(d->colsum_kv)), "attn_bwd: column-sum buffers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long nrow = (long)a.B * a.H * a.nq;
     // delta = rowsum(dO * O): the bf16 query-major kernel produces it itself
@@ -999,20 +1075,20 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
         const int lds_k = 2 * NQP * (a.hd * 2 + 16) + 2 * NQP * 4;
         CAPDEC_CHECK(lds_q <= 160 * 1024 && lds_k <= 160 * 1024, "attn_bwd(bf16): sequence %d too long for the LDS-resident design (hd=%d)", a.S, a.hd);
         dim3 block(256);
-        if (a.nq > 64 && 2 * lds_q <= 160 * 1024) {
+        if (pl.seq_q) {
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, true>, 2 * lds_q);
                         hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, true>), dim3(a.B * a.H), dim3(512), 2 * lds_q, st, a));
         } else if (a.nq > 0) {
-            const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;
-            dim3 gq(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), bq(64 * nwaves);
+            const int nwaves = pl.nwaves_q;
+            dim3 gq(a.B * a.H, pl.nyq), bq(64 * nwaves);
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false>, lds_q); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false>), gq, bq, lds_q, st, a));
         }
-        if (a.nq > 64 && a.S > 128) {
+        if (pl.seq_kv) {
             // many queries staged per workgroup: stage them once per (sequence, head) and walk every key tile
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, true>, lds_k);
                         hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, true>), dim3(a.B * a.H), dim3(512), lds_k, st, a));
         } else {
-            dim3 gk(a.B * a.H, (a.S + 63) / 64);
+            dim3 gk(a.B * a.H, pl.nyk);
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, false>, lds_k); hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, false>), gk, block, lds_k, st, a));
         }
     } else {

@@ -234,10 +234,24 @@ def attn_fwd_packed(qkv, o, lse, B, H, S, hd, *, q_start=0, nq=None, mask_mode=M
     check(_lib.load().capdec_attn_fwd(C.byref(desc), _st()), "capdec_attn_fwd")
 
 
+def attn_bwd_colsum_rows(B, S, nq, hd):
+    """(rows of colsum_q, rows of colsum_kv) for attn_bwd_packed with these shapes."""
+    qr, kr = C.c_long(0), C.c_long(0)
+    _lib.load().capdec_attn_bwd_colsum_rows(B, S, nq, hd, C.byref(qr), C.byref(kr))
+    return qr.value, kr.value
+
+
 def attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, *, q_start=0, nq=None, mask_mode=MASK_NONE, prefix_len=0,
-                    drop: Dropout = NO_DROPOUT, dq_scale=1.0):
+                    drop: Dropout = NO_DROPOUT, dq_scale=1.0, colsum_q=None, colsum_kv=None):
+    """colsum_q [rows_q, H*hd] / colsum_kv [rows_kv, 2*H*hd] (f32, optional; rows from attn_bwd_colsum_rows): per-workgroup
+    column sums of dQ and dK | dV, whose sums over the rows are the packed projection's bias gradient."""
     d = H * hd
     nq = S - q_start if nq is None else nq
+    if colsum_q is not None or colsum_kv is not None:
+        require_cuda(colsum_q, colsum_kv)
+        qr, kr = attn_bwd_colsum_rows(B, S, nq, hd)
+        assert colsum_q is None or (colsum_q.dtype == torch.float32 and colsum_q.shape == (qr, d) and colsum_q.is_contiguous())
+        assert colsum_kv is None or (colsum_kv.dtype == torch.float32 and colsum_kv.shape == (kr, 2 * d) and colsum_kv.is_contiguous())
     desc = AttnBwdDesc()
     s3, s1 = packed_strides(B, d, hd, 3 * d), packed_strides(B, d, hd, d)
     _fill_attn(desc.fwd, qkv, qkv[:, d:], qkv[:, 2 * d:], o, (s3, s3, s3, s1), B, H, S, hd, q_start, nq, mask_mode, prefix_len, drop, lse)
@@ -247,6 +261,7 @@ def attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, *, q_start=0, n
     desc.dv, (desc.dv_bs, desc.dv_hs, desc.dv_ss) = ptr(dqkv[:, 2 * d:]), s3
     desc.dq_scale = dq_scale
     desc.delta = ptr(delta)
+    desc.colsum_q, desc.colsum_kv = ptr(colsum_q), ptr(colsum_kv)
     check(_lib.load().capdec_attn_bwd(C.byref(desc), _st()), "capdec_attn_bwd")
 
 

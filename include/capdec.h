@@ -202,9 +202,16 @@ typedef struct {
     void* dv; long dv_bs, dv_hs, dv_ss;
     float dq_scale;          /* dq is multiplied by this (hd^-0.5 when q was pre-scaled) */
     float* delta;
+    /* optional (bf16 only), both f32 and 16-byte aligned: column sums of dq per 16-row tile -> colsum_q [q_rows, H*hd]
+     * (column h*hd + c) and of dk | dv -> colsum_kv [kv_rows, 2*H*hd], rows from capdec_attn_bwd_colsum_rows.  Summed
+     * over their rows (capdec_colsum) they are the bias gradient of the packed QKV projection (decoder.py:54's
+     * in_proj_bias) without another pass over dq / dk / dv. */
+    float* colsum_q; float* colsum_kv;
 } capdec_attn_bwd_desc;
 
 int capdec_attn_bwd(const capdec_attn_bwd_desc* desc, void* stream);
+/* rows of the two column-sum buffers above for a call with these shapes: B * ceil(nq/16) and B * ceil(S/16) */
+void capdec_attn_bwd_colsum_rows(int B, int S, int nq, int hd, long* q_rows, long* kv_rows);
 
 /* One query row per sequence against a K/V cache [B][H][2][smax][hd]
  * (greedy decoding; no reference counterpart: the reference has no generation).

@@ -682,6 +682,17 @@ def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
     close(dqkv[:, :d], qr.grad[:, :d], tol * 1.5, "dq")
     close(dqkv[:, d:2 * d], qr.grad[:, d:2 * d], tol * 1.5, "dk")
     close(dqkv[:, 2 * d:], qr.grad[:, 2 * d:], tol * 1.5, "dv")
+    if dtype == torch.bfloat16:
+        # the same call leaving per-tile column sums of dQ and dK | dV: outputs unchanged, sums = those of the gradients
+        rq, rk = ops.attn_bwd_colsum_rows(B, S, S, hd)
+        csq, cskv = torch.full((rq, d), float("nan"), device=DEV), torch.full((rk, 2 * d), float("nan"), device=DEV)
+        dqkv2 = torch.full_like(qkv, float("nan"))
+        ops.attn_bwd_packed(qkv, o, lse, dout, dqkv2, delta, B, H, S, hd, mask_mode=mode, prefix_len=prefix, drop=drop, dq_scale=0.5,
+                            colsum_q=csq, colsum_kv=cskv)
+        assert torch.equal(dqkv2[:, d:], dqkv[:, d:])
+        close(dqkv2[:, :d], 0.5 * qr.grad[:, :d], tol * 1.5, "dq, scaled")
+        close(csq.sum(0), 0.5 * qr.grad[:, :d].sum(0), tol, "column sums of dq")
+        close(cskv.sum(0), qr.grad[:, d:].sum(0), tol, "column sums of dk | dv")
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
@@ -705,6 +716,14 @@ def test_attention_query_range(dtype, tol, S, hd, nq):
     delta = torch.empty(B * H * S, device=DEV)
     ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, q_start=S - nq, nq=nq)
     close(dqkv, qr.grad, tol * 1.5, "dqkv")
+    if dtype == torch.bfloat16:
+        rq, rk = ops.attn_bwd_colsum_rows(B, S, nq, hd)
+        csq, cskv = torch.full((rq, d), float("nan"), device=DEV), torch.full((rk, 2 * d), float("nan"), device=DEV)
+        dqkv2 = torch.zeros_like(qkv)
+        ops.attn_bwd_packed(qkv, o, lse, dout, dqkv2, delta, B, H, S, hd, q_start=S - nq, nq=nq, colsum_q=csq, colsum_kv=cskv)
+        assert torch.equal(dqkv2, dqkv)
+        close(csq.sum(0), qr.grad[:, :d].sum(0), tol, "column sums of dq")
+        close(cskv.sum(0), qr.grad[:, d:].sum(0), tol, "column sums of dk | dv")
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
