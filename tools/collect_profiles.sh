@@ -17,6 +17,7 @@ timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pcol/pw
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pcol/pm -o pm -- python3 bench.py --steps 4 --warmup 2 --no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --spinup-steps 0 > $O/pm${V}.log 2>&1
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pcol/kss -o kss -- python3 bench.py --scaled-only --steps 5 --warmup 2 --spinup-steps 0 > $O/kss${V}.log 2>&1
 cp $(find $O/pcol/kss -name "*kernel_stats.csv" | head -1) $O/scaled_kernel_stats_v${V}.csv
+python tools/step_timeline.py $(find $O/pcol/kss -name "*kernel_trace.csv" | head -1) > $O/scaled_step_timeline_v${V}.txt
 find $O/pcol -name "*.csv" | head -20
 cp $(find $O/pcol/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_v${V}.csv
 python tools/step_timeline.py $(find $O/pcol/ks -name "*kernel_trace.csv" | head -1) > $O/step_timeline_v${V}.txt
