@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-fold-norm1", action="store_true", help="block 0's norm1 applied as written (A/B of folding its affine into in_proj)")
     ap.add_argument("--no-ce-row-reference", action="store_true",
                     help="softmax numerators kept per 64-column slot and turned into d(logits) by a pass of its own (A/B)")
+    ap.add_argument("--no-ce-bias-in-wgrad", action="store_true",
+                    help="vocabulary bias gradient by a pass over the numerators instead of as a column of the weight-gradient product (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
@@ -295,6 +297,8 @@ def main():
             opts.vocab_slab = args.vocab_slab
         if args.no_ce_row_reference:
             opts.ce_row_reference = False
+        if args.no_ce_bias_in_wgrad:
+            opts.ce_bias_in_wgrad = False
         if args.no_wgrad_stream:
             opts.wgrad_stream = False
         torch.manual_seed(42)                                           # config.py:27,41

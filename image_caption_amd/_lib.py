@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
         ("kv_smax", c_int), ("kv_s0", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_long),
         ("row_scale", c_void_p),
+        ("kvec", c_void_p), ("kvec_out", c_void_p),
     ]
 
 
@@ -145,7 +146,7 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_ref_prepare": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int,
-                                                 c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "capdec_colsum_weighted": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, c_void_p, c_long, c_void_p]),

@@ -57,6 +57,8 @@ struct GemmArgs {
     float* colpart; long ld_colpart;  // CE backward: per-(64-row group) column sums, [ceil(M/64)][ld_colpart]
     int split_k; long split_stride;    // split-K: blockIdx.y owns a K range and writes slab C + y*split_stride
     unsigned long long* stamps;      // diagnostic: 8 clock stamps per workgroup, NULL in normal use
+    // one more column of a plain product: kvec_out[y * kvec_out_stride + m] = sum over the workgroup's k range of A(m,k) * kvec[k]
+    const bf16_t* kvec; float* kvec_out; long kvec_out_stride;
 };
 
 // ------------------------------------------------------------------ tile order
@@ -1052,7 +1054,21 @@ template <int TJ> struct PipeGeo {
 // s_waitcnt immediate (gfx9 layout: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8]); expcnt is left alone
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8); }
 
-template <bool A_TR, bool B_TR, int EPI, int TJ>
+// KVEC: the workgroups of the first tile column also form A . kvec (one more column of the product, a [K] vector that is
+// kept in LDS behind the ring): per k-step one extra MFMA per 16 rows, whose B-side fragment holds kvec's 32 values in
+// the lanes of column 0 and zeros elsewhere (those lanes read a zero slot), accumulated in arch VGPRs.  The two waves
+// that share a row block (and its A fragments) take alternate 16-row blocks of it.
+constexpr int KVEC_BYTES = 16384 + 64;      // up to 8192 k per workgroup, + the zero slot
+__device__ __forceinline__ u32x4 lds_read_b128_opaque(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void mfma_inplace_v(f32x4& c, const u32x4& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(__builtin_bit_cast(u32x4, b)));
+}
+
+template <bool A_TR, bool B_TR, int EPI, int TJ, bool KVEC = false>
 __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = PipeGeo<TJ>;
@@ -1094,6 +1110,33 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
         kt0 = blockIdx.y * kper;
         nk = max(0, min(kper, nk_total - kt0));
         p.C = (float*)p.C + (long)blockIdx.y * p.split_stride;
+    }
+    // KVEC: this workgroup's k range of the vector -> LDS (zeros past K), before the ring starts: ordinary loads, complete
+    // before the first DMA is issued, so the counted waits below see DMAs only
+    const bool do_kvec = KVEC && tile_n == 0;
+    unsigned gaddr = 0, gstride = 0;
+    u32x4 gf[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    f32x4 bacc[KVEC ? 4 : 1];
+    if constexpr (KVEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        char* kv = smem + G::LDS;
+        if (do_kvec) {
+            const long k0 = (long)kt0 * DBK;
+            for (int c = tid * 8; c < nk * DBK; c += 256 * 8) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = k0 + c + e < p.K ? p.kvec[k0 + c + e] : (bf16_t)0.f;
+                *reinterpret_cast<bf16x8*>(kv + c * 2) = v;
+            }
+            if (tid < 4) *reinterpret_cast<u32x4*>(kv + 16384 + tid * 16) = u32x4{0, 0, 0, 0};
+        }
+        __syncthreads();
+        // lanes of column 0 walk the vector, 32 values (64 bytes) per k-step, 8 per lane group; the others stay on the zero slot
+        const bool col0 = (lane & 15) == 0;
+        gaddr = lds_addr(kv) + (col0 ? (unsigned)((lane >> 4) * 16) : 16384u);
+        gstride = col0 ? 64u : 0u;
+        if (do_kvec) { gf[0] = lds_read_b128_opaque(gaddr); gaddr += gstride; }
     }
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
     // all NST stages go out at once; a stage index past the last k-tile still issues its (harmless) loads, so that the
@@ -1146,7 +1189,7 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
     // One step: MFMAs on the fragments of stage kt (B: cbf; last A: ca7, the others fa[0..6]) while those of stage kt+1
     // are read (B: nb; last A: na7) and the slot stage kt occupied is refilled with stage kt+NST.  Two steps with the
     // buffer roles exchanged make one pass of the loop, so no fragment is ever moved between registers.
-    auto step = [&](bf16x8 (&cbf)[TJ], bf16x8 (&nb)[TJ], bf16x8& ca7, bf16x8& na7) {
+    auto step = [&](bf16x8 (&cbf)[TJ], bf16x8 (&nb)[TJ], bf16x8& ca7, bf16x8& na7, u32x4& cg, u32x4& ng) {
         // This wave's share of stage kt+1 has landed (NST-2 younger stages may stay in flight) and its fragments of stage
         // kt are in registers; after the barrier that holds for every wave, i.e. stage kt+1 is readable and stage kt's
         // slot free.  (The builtin, so that the compiler knows the fragments are in.)
@@ -1179,15 +1222,24 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
                     else dma_piece(rsb, offb[i - PA], wst + G::A_BYTES + (4 * (i - PA) + wave) * 1024);
                 }
             }
+            if constexpr (KVEC) {
+                // the vector's product for this row block, before the block's A fragment is replaced (next row, j = TJ/2 - 1);
+                // the next step's 32 values are requested once per step (a read past the range fetches ring bytes nobody uses)
+                if (do_kvec) {
+                    if ((i & 1) == wc) mfma_inplace_v(bacc[i >> 1], cg, i < 7 ? fa[i] : ca7);
+                    if (i == 0) { ng = lds_read_b128_opaque(gaddr); gaddr += gstride; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        step(fb[0], fb[1], fa[7], fa7);
-        step(fb[1], fb[0], fa7, fa[7]);
+        step(fb[0], fb[1], fa[7], fa7, gf[0], gf[1]);
+        step(fb[1], fb[0], fa7, fa[7], gf[1], gf[0]);
     }
-    if (kt < nk) step(fb[0], fb[1], fa[7], fa7);
+    if (kt < nk) step(fb[0], fb[1], fa[7], fa7, gf[0], gf[1]);
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the fragment reads of the stage past the end are in
     // Those last reads feed nothing, and to the compiler an inline-assembly read is complete when issued: without the
     // uses below it hands their destination registers to the next value at once -- in the last step that was the
@@ -1201,11 +1253,22 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
         asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[0][j])));
         asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[1][j])));
     }
+    if constexpr (KVEC) { asm volatile("" ::"v"(gf[0])); asm volatile("" ::"v"(gf[1])); }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last MFMAs (opaque to the compiler) have written back
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // trailing refills and fragment reads are done before LDS is reused
     __syncthreads();
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
 
+    if constexpr (KVEC) {
+        // row 0 of each extra tile: lanes 0..15 hold element 0 for the block's 16 rows
+        if (do_kvec && lane < 16) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int m = m0 + wr * 128 + (2 * ii + wc) * 16 + lane;
+                if (m < p.M) p.kvec_out[(long)blockIdx.y * p.kvec_out_stride + m] = bacc[ii][0];
+            }
+        }
+    }
     // the wave's block goes through its private 64x64 LDS tile one 64x64 piece at a time
     float* cs = reinterpret_cast<float*>(smem + wave * CS_WAVE_BYTES);
 #pragma unroll
@@ -1298,6 +1361,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // ------------------------------------------------------------------ launch
 unsigned long long* g_stamps = nullptr;
+thread_local bool t_kvec_done = false;      // the last launch_gemm formed A . kvec next to the product
 constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 pipelined 256x256, 7 pipelined 256x128)
@@ -1384,6 +1448,17 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(256), PipeGeo<TJ>::LDS, st, a);     \
     } while (0)
 #define CAPDEC_QUAD_LAUNCH(AT, BT) CAPDEC_PIPE_LAUNCH(AT, BT, EPI_STD, 8, wide_tiles)
+#define CAPDEC_QUAD_KVEC_LAUNCH()                                                                      \
+    do {                                                                                               \
+        auto kfn = gemm_bf16_pipe_kernel<true, true, EPI_STD, 8, true>;                                \
+        static bool attr_set = false;                                                                  \
+        if (!attr_set) {                                                                               \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                           \
+        }                                                                                              \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(wide_tiles), split), dim3(256), PipeGeo<8>::LDS + KVEC_BYTES, st, a); \
+        t_kvec_done = true;                                                                            \
+    } while (0)
         if (kern == KERN_TALLP) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_PIPE_LAUNCH(true, true, EPI_STD, 4, big_tiles);
@@ -1399,7 +1474,10 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         } else
         if (kern == KERN_QUAD) {
             if constexpr (EPI == EPI_STD) {
-                if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);
+                // the vector product rides along when a workgroup's k range fits the LDS behind the ring
+                const bool kvec_fits = a.kvec && a.kvec_out && ((a.K + DBK - 1) / DBK + split - 1) / split * DBK <= 8192;
+                if (a.a_kmajor && a.b_kmajor && kvec_fits) CAPDEC_QUAD_KVEC_LAUNCH();
+                else if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);
                 else if (a.a_kmajor) CAPDEC_QUAD_LAUNCH(true, false);
                 else if (a.b_kmajor) CAPDEC_QUAD_LAUNCH(false, true);
                 else CAPDEC_QUAD_LAUNCH(false, false);
@@ -1426,6 +1504,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 #undef CAPDEC_GEMM_CASE
 #undef CAPDEC_RING_LAUNCH
 #undef CAPDEC_QUAD_LAUNCH
+#undef CAPDEC_QUAD_KVEC_LAUNCH
 #undef CAPDEC_PIPE_LAUNCH
     } else {
         static bool attr_set = false;
@@ -1633,7 +1712,7 @@ __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowfla
 __global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, long ld, const bf16_t* h, long ldh, int d,
                                                                   const int64_t* labels, int ce_B, int ce_L, long M,
                                                                   const float* lse, const float* rowref, float gscale,
-                                                                  bf16_t* hs, long ldhs, float* rowscale) {
+                                                                  bf16_t* hs, long ldhs, float* rowscale, bf16_t* rowscale_lp) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -1648,10 +1727,28 @@ __global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, 
     }
     if (lane == 0) {
         rowscale[m] = g;
+        if (rowscale_lp) rowscale_lp[m] = (bf16_t)g;
         const long l = m / ce_B, b = m - l * ce_B;
         bf16_t* pl = probs + m * ld + labels[b * ce_L + l];
         *pl = (bf16_t)((float)*pl - __expf(-e));
     }
+}
+
+// out[m] = sum over the split-K slabs of the vector product, in slab order
+__global__ void kvec_reduce_kernel(const float* slabs, int split, long M, float* out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float a = 0.f;
+    for (int y = 0; y < split; ++y) a += slabs[(long)y * M + m];
+    out[m] = a;
+}
+// out[m] = sum_k A(m, k) * v[k] for products whose kernel does not form it on the way (small or oddly shaped ones)
+__global__ void kvec_plain_kernel(const bf16_t* A, long lda, int a_kmajor, long M, int K, const bf16_t* v, float* out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a = fmaf((float)(a_kmajor ? A[(long)k * lda + m] : A[m * lda + k]), (float)v[k], a);
+    out[m] = a;
 }
 
 // x[m, :] *= s[m]
@@ -1858,21 +1955,28 @@ namespace { thread_local bool t_row_scaled = false; }      // the last product a
 static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream);
 
 extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
-    if (!d || !d->row_scale) return gemm_bias_act_impl(d, stream);
+    if (!d || (!d->row_scale && !d->kvec)) return gemm_bias_act_impl(d, stream);
     CAPDEC_CHECK(!d->accumulate && !d->bias && d->col_scale_n == 0 && d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual &&
-                 !d->gate && !d->aux_out && !d->colsum && !d->kv_cache, "gemm: row_scale goes with plain products only");
-    t_row_scaled = false;
+                 !d->gate && !d->aux_out && !d->colsum && !d->kv_cache, "gemm: row_scale / kvec go with plain products only");
+    CAPDEC_CHECK(!d->kvec || (d->kvec_out && d->in_dtype == CAPDEC_BF16), "gemm: kvec needs kvec_out and bf16 operands");
+    t_row_scaled = false; t_kvec_done = false;
     const int rc = gemm_bias_act_impl(d, stream);
-    if (rc || t_row_scaled || d->M == 0 || d->N == 0) { t_row_scaled = true; return rc; }
-    // the kernel that ran has no row factor in its epilogue: one more pass over C
-    const long total = (long)d->M * d->N;
-    const int nb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    if (d->out_dtype == CAPDEC_BF16)
-        hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16_t*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
-    else
-        hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (float*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
+    if (rc || d->M == 0 || d->N == 0) { t_row_scaled = true; t_kvec_done = true; return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    if (d->kvec && !t_kvec_done)          // the kernel that ran does not form the vector product
+        hipLaunchKernelGGL(kvec_plain_kernel, dim3((unsigned)((d->M + 255) / 256)), dim3(256), 0, st, (const bf16_t*)d->A, d->lda, d->a_kmajor,
+                           (long)d->M, d->K, (const bf16_t*)d->kvec, d->kvec_out);
+    if (d->row_scale && !t_row_scaled) {
+        // the kernel that ran has no row factor in its epilogue: one more pass over C
+        const long total = (long)d->M * d->N;
+        const int nb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        if (d->out_dtype == CAPDEC_BF16)
+            hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (bf16_t*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
+        else
+            hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(nb), dim3(256), 0, st, (float*)d->C, d->ldc, (long)d->M, d->N, d->row_scale);
+    }
     CAPDEC_LAUNCH_CHECK();
-    t_row_scaled = true;
+    t_row_scaled = true; t_kvec_done = true;
     return CAPDEC_OK;
 }
 
@@ -1905,6 +2009,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             t1.A = (const char*)d->A + (d->a_kmajor ? m0 : m0 * d->lda) * esz;
             t1.C = (char*)d->C + m0 * d->ldc * osz;
             if (d->row_scale) t1.row_scale = d->row_scale + m0;
+            if (d->kvec_out) t1.kvec_out = d->kvec_out + m0;
             int rc = capdec_gemm_bias_act(&h1, stream);
             if (rc) return rc;
             return capdec_gemm_bias_act(&t1, stream);
@@ -1930,6 +2035,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     a.colsum = d->colsum;
     a.kv_cache = d->kv_cache; a.kv_q = d->kv_q; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
     a.kv_smax = d->kv_smax; a.kv_s0 = d->kv_s0;
+    a.kvec = (const bf16_t*)d->kvec; a.kvec_out = d->kvec_out; a.kvec_out_stride = 0;
     if (a.kv_cache) {
         CAPDEC_CHECK(a.kv_d > 0 && a.kv_B > 0 && a.kv_H > 0 && a.kv_hd > 0 && a.kv_H * a.kv_hd == a.kv_d && (a.kv_hd % 4) == 0,
                      "gemm: inconsistent kv scatter geometry");
@@ -1948,8 +2054,12 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
         const long wide = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
         // at most 32 slabs, each at least 8 k-tiles deep, as many as the workspace holds
         const long slab_bytes = (long)a.M * a.N * 4;
+        // with a vector product: up to 32 slabs of M floats at the end of the workspace
+        const long kv_bytes = a.kvec ? 32L * a.M * 4 : 0;
+        const long ws_bytes = d->workspace_bytes > kv_bytes ? (d->workspace_bytes - kv_bytes) & ~15L : 0;
+        float* kv_slabs = a.kvec ? (float*)((char*)d->workspace + ws_bytes) : nullptr;
         long maxsp = nkt / 8 < 32 ? nkt / 8 : 32;
-        if (d->workspace_bytes / slab_bytes < maxsp) maxsp = d->workspace_bytes / slab_bytes;
+        if (ws_bytes / slab_bytes < maxsp) maxsp = ws_bytes / slab_bytes;
         // 256x256 tiles (one workgroup per CU) when some split gives (nearly) every CU one; else 256x128 / 128x128 tiles
         const bool wide_possible = ring_ok && a.K >= 2048 && wide * maxsp >= WIDE_MIN_WGS;
         const bool tall_possible = !a.a_kmajor && a.K >= 512 && (a.K % 32) == 0;
@@ -1964,10 +2074,11 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             if (eff > best + 0.03) { best = eff; split = sp; }
         }
         const long slab = (long)a.M * a.N;
-        if (split > 1 && d->workspace_bytes >= split * slab * 4) {
+        if (split > 1 && ws_bytes >= split * slab * 4) {
             GemmArgs b = a;
             b.C = d->workspace; b.ldc = a.N; b.out_dtype = CAPDEC_F32; b.accumulate = 0;
             b.split_k = (int)split; b.split_stride = slab;
+            if (a.kvec) { b.kvec_out = kv_slabs; b.kvec_out_stride = a.M; }
             b.fast_epi = (a.N % 4) == 0 && ((slab * 4) % 16) == 0 && aligned16(d->workspace) ? 4 : 0;
             int rc = launch_gemm<EPI_STD>(b, d->in_dtype, (hipStream_t)stream);
             if (rc) return rc;
@@ -1976,6 +2087,9 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
                 hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (bf16_t*)a.C, a.ldc, a.accumulate, d->row_scale);
             else
                 hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (float*)a.C, a.ldc, a.accumulate, d->row_scale);
+            if (a.kvec && t_kvec_done)
+                hipLaunchKernelGGL(kvec_reduce_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                   (const float*)kv_slabs, (int)split, (long)a.M, d->kvec_out);
             CAPDEC_LAUNCH_CHECK();
             if (d->row_scale) t_row_scaled = true;
             return CAPDEC_OK;
@@ -2160,14 +2274,14 @@ extern "C" int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long
                                                 const void* h, long ldh, int d,
                                                 const int64_t* labels, int B, int L,
                                                 const float* lse, const float* rowref, float gscale,
-                                                void* h_scaled, long ld_hs, float* rowscale, void* stream) {
+                                                void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16, void* stream) {
     CAPDEC_CHECK(probs && h && labels && lse && rowref && h_scaled && rowscale, "logits_ce_bwd_ref_prepare: null pointer");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_ref_prepare: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(ld_probs >= V && (d % 8) == 0 && (ldh % 8) == 0 && (ld_hs % 8) == 0 && ld_hs >= d && aligned16(h) && aligned16(h_scaled),
                  "logits_ce_bwd_ref_prepare: rows of h / h_scaled must be 16-byte aligned, d a multiple of 8");
     if (M == 0) return CAPDEC_OK;
     hipLaunchKernelGGL(ce_ref_bwd_prepare_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)probs, ld_probs,
-                       (const bf16_t*)h, ldh, d, labels, B, L, M, lse, rowref, gscale, (bf16_t*)h_scaled, ld_hs, rowscale);
+                       (const bf16_t*)h, ldh, d, labels, B, L, M, lse, rowref, gscale, (bf16_t*)h_scaled, ld_hs, rowscale, (bf16_t*)rowscale_bf16);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -55,6 +55,7 @@ class EngineOptions:
     dl_budget_bytes: int = 16 << 30               # cap on the d(logits) slab buffer (the whole vocabulary fits up to batch 5000 per GPU)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
+    ce_bias_in_wgrad: bool = True                 # ... and the vocabulary bias gradient taken as one more column of the weight-gradient product
     ce_row_reference: bool = True                 # ... kept against one reference per row (the label's logit), so that d(logits) is a
                                                   # row factor times the numerators and the backward products read them as they are
     composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
@@ -472,14 +473,21 @@ class DecoderEngine:
             # own reads and the weighted column sums for the bias
             hs = self.buf("head_in_scaled", (Mh, d), cdt, dev)
             rowscale = self.buf("ce_rowscale", (Mh,), torch.float32, dev)
+            rowscale_lp = self.buf("ce_rowscale_lp", (Mh,), cdt, dev)
             with self._span("ce_bwd_prepare"):
-                ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B, L, lse, rowref, gscale, hs, rowscale)
-            # on this stream: the products' workgroups take a CU's whole register file, so a pass running beside them
-            # only takes CUs away from them (on a second stream it cost the weight gradient twice its own duration)
-            with self._span("ce_bias_grad"):
-                ops.colsum_weighted(dl[:, :V], rowscale, gb, bws)
-            with self._span("head_wgrad_slab"):
-                ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws)
+                ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B, L, lse, rowref, gscale, hs, rowscale, rowscale_lp)
+            if self.opt.ce_bias_in_wgrad:
+                # the bias gradient is one more column of the weight-gradient product (numerators^T . rowscale): formed by that
+                # product's kernel on the way instead of by a pass over the numerators
+                with self._span("head_wgrad_slab"):
+                    ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws, kvec=rowscale_lp, kvec_out=gb)
+            else:
+                # on this stream: the products' workgroups take a CU's whole register file, so a pass running beside them
+                # only takes CUs away from them (on a second stream it cost the weight gradient twice its own duration)
+                with self._span("ce_bias_grad"):
+                    ops.colsum_weighted(dl[:, :V], rowscale, gb, bws)
+                with self._span("head_wgrad_slab"):
+                    ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws)
             if on_grad_ready is not None:
                 on_grad_ready(HEAD_W, 0, V)
             kk = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V

@@ -160,10 +160,10 @@ def _ld(t: torch.Tensor) -> int:
 
 def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
          act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
-         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None):
+         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None, kvec=None, kvec_out=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
     B is [N,K] (or [K,N] if b_kmajor)."""
-    require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache, row_scale)
+    require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache, row_scale, kvec, kvec_out)
     assert A.dtype == B.dtype
     if M is None:
         M = A.shape[1] if a_kmajor else A.shape[0]
@@ -201,6 +201,10 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
     if row_scale is not None:
         assert row_scale.dtype == torch.float32 and row_scale.numel() == M and row_scale.is_contiguous()
         d.row_scale = ptr(row_scale)
+    if kvec is not None:
+        assert kvec.dtype == A.dtype == torch.bfloat16 and kvec.numel() == K and kvec.is_contiguous()
+        assert kvec_out.dtype == torch.float32 and kvec_out.numel() >= M and kvec_out.is_contiguous()
+        d.kvec, d.kvec_out = ptr(kvec), ptr(kvec_out)
     check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
     return Cout
 
@@ -303,15 +307,16 @@ def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, 
                                                workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd_ref")
 
 
-def logits_ce_bwd_ref_prepare(probs, V, h, labels, B, L, lse, rowref, gscale, h_scaled, rowscale):
+def logits_ce_bwd_ref_prepare(probs, V, h, labels, B, L, lse, rowref, gscale, h_scaled, rowscale, rowscale_bf16=None):
     """In place: the label's numerator of every row is patched so that d(logits) = rowscale[m] * probs[m, :];
     h_scaled = rowscale[:, None] * h (bf16), rowscale [M] f32."""
-    require_cuda(probs, h, labels, lse, rowref, h_scaled, rowscale)
+    require_cuda(probs, h, labels, lse, rowref, h_scaled, rowscale, rowscale_bf16)
+    assert rowscale_bf16 is None or (rowscale_bf16.dtype == torch.bfloat16 and rowscale_bf16.numel() == h.shape[0])
     M, d = h.shape
     assert probs.shape[0] == M and h_scaled.shape == (M, d) and h_scaled.dtype == h.dtype == torch.bfloat16
     assert rowscale.dtype == torch.float32 and rowscale.numel() == M
     check(_lib.load().capdec_logits_ce_bwd_ref_prepare(ptr(probs), _ld(probs), M, V, ptr(h), _ld(h), d, ptr(labels), B, L,
-                                                       ptr(lse), ptr(rowref), gscale, ptr(h_scaled), _ld(h_scaled), ptr(rowscale), _st()),
+                                                       ptr(lse), ptr(rowref), gscale, ptr(h_scaled), _ld(h_scaled), ptr(rowscale), ptr(rowscale_bf16), _st()),
           "capdec_logits_ce_bwd_ref_prepare")
 
 

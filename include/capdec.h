@@ -165,6 +165,10 @@ typedef struct {
     void* workspace; long workspace_bytes;
     /* optional [M] f32: C = diag(row_scale) (A B); plain products only (no epilogue term, no accumulate) */
     const float* row_scale;
+    /* optional, plain bf16 products only: kvec [K] bf16, kvec_out [M] f32 (OVERWRITTEN) = sum_k A(m,k) * kvec[k], one more
+     * column of the product formed on the way where the kernel allows (the vocabulary bias gradient next to the weight
+     * gradient).  With a split-K workspace, 32*M*4 bytes at its end are used for this. */
+    const void* kvec; float* kvec_out;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);
@@ -281,12 +285,13 @@ int capdec_logits_ce_fwd_ref(const void* h, const void* W, const float* bias, in
  * d(logits)[m,v] = g[m] * probs'[m,v], probs' = probs except probs'[m,label] = probs[m,label] - exp(lse[m] - rowref[m])
  * (patched IN PLACE here).  Writes rowscale[m] = g[m] ([M] f32) and h_scaled[m,:] = g[m] * h[m,:] (bf16 [M, ld_hs]):
  *   d head.weight = probs'^T h_scaled,  d h = diag(rowscale) (probs' W)  (capdec_gemm_desc.row_scale),
- *   d head.bias = capdec_colsum_weighted(probs', rowscale). */
+ *   d head.bias = capdec_colsum_weighted(probs', rowscale), or, with rowscale_bf16 (optional [M] bf16 copy of g) as
+ *   capdec_gemm_desc.kvec of the weight-gradient product, one more column of that product. */
 int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
                                      const void* h, long ldh, int d,
                                      const int64_t* labels, int B, int L,
                                      const float* lse, const float* rowref, float gscale,
-                                     void* h_scaled, long ld_hs, float* rowscale, void* stream);
+                                     void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16, void* stream);
 /* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
  * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
 int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,

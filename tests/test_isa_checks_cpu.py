@@ -17,3 +17,29 @@ def test_no_instruction_touches_an_inflight_fragment_register():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "gemm_bf16_pipe_kernel" in r.stdout          # the kernels with inline-assembly reads were found and walked
+
+
+def _run_checker(tmp_path, body):
+    import sys
+    src = tmp_path / "k.s"
+    src.write_text("_Z6kernelv:\n" + body + "\ts_endpgm\n")
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py"), str(src)], capture_output=True, text=True)
+
+
+def test_checker_finds_a_reused_register_and_follows_branches(tmp_path):
+    """The checker itself: a register written while an inline-assembly read into it is in flight is reported, also when
+    the write sits behind a branch; a path on which the wait has happened is not."""
+    read = "\t;;#ASMSTART\n\tds_read_b64_tr_b16 v[10:11], v12\n\t;;#ASMEND\n"
+    r = _run_checker(tmp_path, read + "\tv_mov_b32_e32 v11, v3\n\ts_waitcnt lgkmcnt(0)\n")
+    assert r.returncode == 1 and "1 instruction(s)" in r.stdout
+    r = _run_checker(tmp_path, read + "\ts_cbranch_scc1 .LBB0_2\n\ts_waitcnt lgkmcnt(0)\n\ts_branch .LBB0_3\n.LBB0_2:\n\tv_add_u32_e32 v10, v1, v2\n"
+                     ".LBB0_3:\n\ts_waitcnt lgkmcnt(0)\n")
+    assert r.returncode == 1 and "1 instruction(s)" in r.stdout
+    r = _run_checker(tmp_path, read + "\ts_waitcnt lgkmcnt(0)\n\ts_cbranch_scc1 .LBB0_2\n\ts_branch .LBB0_3\n.LBB0_2:\n\tv_mov_b32_e32 v11, v3\n.LBB0_3:\n")
+    assert r.returncode == 0 and ": 0 instruction(s)" in r.stdout
+    # a 16-byte read between the assembly markers counts, the compiler's own (which it waits for itself) does not
+    r = _run_checker(tmp_path, "\t;;#ASMSTART\n\tds_read_b128 v[4:7], v12\n\t;;#ASMEND\n\tv_mov_b32_e32 v5, v3\n\ts_waitcnt lgkmcnt(0)\n"
+                     + read + "\ts_waitcnt lgkmcnt(0)\n")
+    assert r.returncode == 1
+    r = _run_checker(tmp_path, "\tds_read_b128 v[4:7], v12\n\tv_mov_b32_e32 v5, v3\n" + read + "\ts_waitcnt lgkmcnt(0)\n")
+    assert r.returncode == 0

@@ -302,7 +302,9 @@ def test_logits_ce_row_reference(gemm_mode, mode, B_, L, V, d, with_bias, hot_ro
     # backward pieces
     hs = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
     rowscale = torch.full((M,), float("nan"), device=DEV)
-    ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B_, L, lse, rowref, 1.0 / M, hs, rowscale)
+    rowscale_lp = torch.full((M,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B_, L, lse, rowref, 1.0 / M, hs, rowscale, rowscale_lp)
+    assert torch.equal(rowscale_lp, rowscale.to(torch.bfloat16))
     close(rowscale[:, None] * dl[:, :V].float(), ref_dl, 1e-2, "d(logits) = rowscale * numerators")
     close(hs, rowscale[:, None] * h.float(), 1e-2, "scaled head input")
     assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
@@ -313,12 +315,43 @@ def test_logits_ce_row_reference(gemm_mode, mode, B_, L, V, d, with_bias, hot_ro
     hws = torch.empty(8 * M * d * 4, dtype=torch.uint8, device=DEV)
     ops.gemm(dl, hs, gW, M=V, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=hws)
     close(gW, ref_dl.t() @ h.float(), 1e-2, "weight gradient")
+    # the bias gradient as one more column of that product
+    gW2, dbias2 = torch.full((V, d), float("nan"), device=DEV), torch.full((V,), float("nan"), device=DEV)
+    ops.gemm(dl, hs, gW2, M=V, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=hws, kvec=rowscale_lp, kvec_out=dbias2)
+    assert torch.equal(gW2, gW)
+    close(dbias2, ref_dl.sum(0), 1e-2, "dbias from the weight-gradient product")
     wp = torch.zeros(Vp, d, device=DEV, dtype=torch.bfloat16)
     wp[:V] = w
     for use_ws in (True, False):                                                   # row factor in the split-K fold / as a pass of its own
         dH = torch.full((M, d), float("nan"), device=DEV)
         ops.gemm(dl, wp, dH, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws if use_ws else None, row_scale=rowscale)
         close(dH, ref_dl @ w.float(), 1e-2, "data gradient")
+
+
+@pytest.mark.parametrize("M,N,K,with_ws", [
+    (8192, 2048, 2048, False),          # 256 tiles of 256x256, one launch: the pipelined kernel forms the vector product itself
+    (1024, 1024, 16384, True),          # 16 tiles, split-K through the workspace: slabs of the vector product, summed afterwards
+    (50260, 768, 8192, True),           # the vocabulary weight gradient: whole rounds + a split-K tail, ragged last tile
+    (8192, 2048, 16384, False),         # k range too long for the LDS behind the ring: separate pass
+    (200, 328, 520, False),             # small: separate pass
+])
+def test_gemm_vector_column(M, N, K, with_ws):
+    """kvec_out = A . kvec next to a plain reduction-major product: same C as without it, the vector product to bf16 operand
+    precision."""
+    A = rnd(K, (M + 127) // 128 * 128, dtype=torch.bfloat16, seed=90)[:, :M]          # rows 16-byte aligned, like the numerators
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.1, seed=91)
+    v = rnd(K, dtype=torch.bfloat16, seed=92)
+    ws = torch.empty(8 * max(M, 4096) * N * 4, dtype=torch.uint8, device=DEV) if with_ws else None
+    C0 = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, B, C0, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws)
+    C1 = torch.full((M, N), float("nan"), device=DEV)
+    out = torch.full((M,), float("nan"), device=DEV)
+    ops.gemm(A, B, C1, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws, kvec=v, kvec_out=out)
+    assert torch.equal(C1, C0)
+    close(out, A.float().t() @ v.float(), 2e-3, "vector column")
+    out2 = torch.full((M,), float("nan"), device=DEV)
+    ops.gemm(A, B, C1, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws, kvec=v, kvec_out=out2)
+    assert torch.equal(out2, out)                                       # fixed summation order
 
 
 def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
