@@ -199,7 +199,7 @@ KERNEL_NAMES = {"logits_ce_fwd_kernel": "head_fwd_kernel<2,4,8,4,true,false,3> (
                 "logits_ce_fwd": "capdec_logits_ce_fwd_ref as a whole: label_logit_kernel + head_fwd_kernel + ce_finalize_kernel + ce_ref_fixup_kernel + ce_reduce_kernel",
                 "logits_ce_bwd_slab": "gemm_bf16_dma_kernel<false,false,2,2,2,8,3> (EPI_CE_BWD, 256x128 tiles) + colpart_reduce_kernel",
                 "head_dgrad_slab": "gemm_bf16_pipe_kernel<false,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128, split-K) + splitk_reduce_kernel",
-                "head_wgrad_slab": "gemm_bf16_pipe_kernel<true,true,EPI_STD,8> (256x256 tiles, 4 waves of 128x128)"}
+                "head_wgrad_slab": "gemm_bf16_pipe_kernel<true,true,EPI_STD,8,KVEC> (256x256 tiles, 4 waves of 128x128; the bias gradient rides along as one more column)"}
 
 
 def head_kernel_timing(on):
