@@ -1068,7 +1068,9 @@ __device__ __forceinline__ void mfma_inplace_v(f32x4& c, const u32x4& a, const b
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(__builtin_bit_cast(u32x4, b)));
 }
 
-template <bool A_TR, bool B_TR, int EPI, int TJ, bool KVEC = false>
+// KVEC = 2: the vector is all ones (row sums of A, i.e. column sums of a reduction-major operand): a constant fragment,
+// nothing in LDS, any k range.
+template <bool A_TR, bool B_TR, int EPI, int TJ, int KVEC = 0>
 __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = PipeGeo<TJ>;
@@ -1113,13 +1115,19 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
     }
     // KVEC: this workgroup's k range of the vector -> LDS (zeros past K), before the ring starts: ordinary loads, complete
     // before the first DMA is issued, so the counted waits below see DMAs only
-    const bool do_kvec = KVEC && tile_n == 0;
+    const bool do_kvec = KVEC != 0 && tile_n == 0;
     unsigned gaddr = 0, gstride = 0;
     u32x4 gf[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     f32x4 bacc[KVEC ? 4 : 1];
-    if constexpr (KVEC) {
+    if constexpr (KVEC != 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (KVEC == 2) {
+        const unsigned one2 = (lane & 15) == 0 ? 0x3F803F80u : 0u;      // two bf16 ones in the lanes of column 0
+        gf[0] = gf[1] = u32x4{one2, one2, one2, one2};
+    }
+    if constexpr (KVEC == 1) {
         char* kv = smem + G::LDS;
         if (do_kvec) {
             const long k0 = (long)kt0 * DBK;
@@ -1222,12 +1230,14 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
                     else dma_piece(rsb, offb[i - PA], wst + G::A_BYTES + (4 * (i - PA) + wave) * 1024);
                 }
             }
-            if constexpr (KVEC) {
+            if constexpr (KVEC != 0) {
                 // the vector's product for this row block, before the block's A fragment is replaced (next row, j = TJ/2 - 1);
                 // the next step's 32 values are requested once per step (a read past the range fetches ring bytes nobody uses)
                 if (do_kvec) {
                     if ((i & 1) == wc) mfma_inplace_v(bacc[i >> 1], cg, i < 7 ? fa[i] : ca7);
-                    if (i == 0) { ng = lds_read_b128_opaque(gaddr); gaddr += gstride; }
+                    if constexpr (KVEC == 1) {
+                        if (i == 0) { ng = lds_read_b128_opaque(gaddr); gaddr += gstride; }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1253,13 +1263,13 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
         asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[0][j])));
         asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb[1][j])));
     }
-    if constexpr (KVEC) { asm volatile("" ::"v"(gf[0])); asm volatile("" ::"v"(gf[1])); }
+    if constexpr (KVEC != 0) { asm volatile("" ::"v"(gf[0])); asm volatile("" ::"v"(gf[1])); }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last MFMAs (opaque to the compiler) have written back
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // trailing refills and fragment reads are done before LDS is reused
     __syncthreads();
     if (p.stamps && tid == 0) p.stamps[(long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
 
-    if constexpr (KVEC) {
+    if constexpr (KVEC != 0) {
         // row 0 of each extra tile: lanes 0..15 hold element 0 for the block's 16 rows
         if (do_kvec && lane < 16) {
 #pragma unroll
@@ -1448,15 +1458,15 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(256), PipeGeo<TJ>::LDS, st, a);     \
     } while (0)
 #define CAPDEC_QUAD_LAUNCH(AT, BT) CAPDEC_PIPE_LAUNCH(AT, BT, EPI_STD, 8, wide_tiles)
-#define CAPDEC_QUAD_KVEC_LAUNCH()                                                                      \
+#define CAPDEC_QUAD_KVEC_LAUNCH(MODE)                                                                  \
     do {                                                                                               \
-        auto kfn = gemm_bf16_pipe_kernel<true, true, EPI_STD, 8, true>;                                \
+        auto kfn = gemm_bf16_pipe_kernel<true, true, EPI_STD, 8, MODE>;                                \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(wide_tiles), split), dim3(256), PipeGeo<8>::LDS + KVEC_BYTES, st, a); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(wide_tiles), split), dim3(256), PipeGeo<8>::LDS + (MODE == 1 ? KVEC_BYTES : 0), st, a); \
         t_kvec_done = true;                                                                            \
     } while (0)
         if (kern == KERN_TALLP) {
@@ -1476,7 +1486,8 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
             if constexpr (EPI == EPI_STD) {
                 // the vector product rides along when a workgroup's k range fits the LDS behind the ring
                 const bool kvec_fits = a.kvec && a.kvec_out && ((a.K + DBK - 1) / DBK + split - 1) / split * DBK <= 8192;
-                if (a.a_kmajor && a.b_kmajor && kvec_fits) CAPDEC_QUAD_KVEC_LAUNCH();
+                if (a.a_kmajor && a.b_kmajor && kvec_fits) CAPDEC_QUAD_KVEC_LAUNCH(1);
+                else if (a.a_kmajor && a.b_kmajor && !a.kvec && a.kvec_out) CAPDEC_QUAD_KVEC_LAUNCH(2);       // a vector of ones
                 else if (a.a_kmajor && a.b_kmajor) CAPDEC_QUAD_LAUNCH(true, true);
                 else if (a.a_kmajor) CAPDEC_QUAD_LAUNCH(true, false);
                 else if (a.b_kmajor) CAPDEC_QUAD_LAUNCH(false, true);
@@ -1742,13 +1753,29 @@ __global__ void kvec_reduce_kernel(const float* slabs, int split, long M, float*
     for (int y = 0; y < split; ++y) a += slabs[(long)y * M + m];
     out[m] = a;
 }
-// out[m] = sum_k A(m, k) * v[k] for products whose kernel does not form it on the way (small or oddly shaped ones)
-__global__ void kvec_plain_kernel(const bf16_t* A, long lda, int a_kmajor, long M, int K, const bf16_t* v, float* out) {
-    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+// out[y][m] = sum over k chunk y of A(m, k) * v[k] (v NULL: ones), for products whose kernel does not form it on the way.
+// A block owns 64 values of m; its 4 waves take every 4th k of the chunk, 8 loads in flight each, and are added in wave order.
+__global__ __launch_bounds__(256) void kvec_plain_kernel(const bf16_t* A, long lda, int a_kmajor, long M, int K, const bf16_t* v, float* out, int kchunk) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long m = (long)blockIdx.x * 64 + tx;
+    const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
     float a = 0.f;
-    for (int k = 0; k < K; ++k) a = fmaf((float)(a_kmajor ? A[(long)k * lda + m] : A[m * lda + k]), (float)v[k], a);
-    out[m] = a;
+    if (m < M) {
+        auto at = [&](int k) { return (float)(a_kmajor ? A[(long)k * lda + m] : A[m * lda + k]) * (v ? (float)v[k] : 1.f); };
+        int k = k0 + ty;
+        for (; k + 28 < k1; k += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = at(k + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += t[u];
+        }
+        for (; k < k1; k += 4) a += at(k);
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && m < M) out[(long)blockIdx.y * M + m] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
 }
 
 // x[m, :] *= s[m]
@@ -1955,17 +1982,29 @@ namespace { thread_local bool t_row_scaled = false; }      // the last product a
 static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream);
 
 extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
-    if (!d || (!d->row_scale && !d->kvec)) return gemm_bias_act_impl(d, stream);
+    if (!d || (!d->row_scale && !d->kvec_out)) return gemm_bias_act_impl(d, stream);
     CAPDEC_CHECK(!d->accumulate && !d->bias && d->col_scale_n == 0 && d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual &&
                  !d->gate && !d->aux_out && !d->colsum && !d->kv_cache, "gemm: row_scale / kvec go with plain products only");
-    CAPDEC_CHECK(!d->kvec || (d->kvec_out && d->in_dtype == CAPDEC_BF16), "gemm: kvec needs kvec_out and bf16 operands");
+    CAPDEC_CHECK((!d->kvec || d->kvec_out) && (!d->kvec_out || d->in_dtype == CAPDEC_BF16), "gemm: kvec needs kvec_out, kvec_out bf16 operands");
     t_row_scaled = false; t_kvec_done = false;
     const int rc = gemm_bias_act_impl(d, stream);
     if (rc || d->M == 0 || d->N == 0) { t_row_scaled = true; t_kvec_done = true; return rc; }
     hipStream_t st = (hipStream_t)stream;
-    if (d->kvec && !t_kvec_done)          // the kernel that ran does not form the vector product
-        hipLaunchKernelGGL(kvec_plain_kernel, dim3((unsigned)((d->M + 255) / 256)), dim3(256), 0, st, (const bf16_t*)d->A, d->lda, d->a_kmajor,
-                           (long)d->M, d->K, (const bf16_t*)d->kvec, d->kvec_out);
+    if (d->kvec_out && !t_kvec_done) {     // the kernel that ran does not form the vector product: a pass over A, in up to 32
+                                           // k chunks through the end of the workspace when there is one
+        const long kv_bytes = 32L * d->M * 4;
+        int chunks = 1;
+        float* slabs = d->kvec_out;
+        if (d->workspace && d->workspace_bytes >= kv_bytes && d->K >= 4096) {
+            chunks = 32;
+            slabs = (float*)((char*)d->workspace + ((d->workspace_bytes - kv_bytes) & ~15L));
+        }
+        const int kchunk = (d->K + chunks - 1) / chunks;
+        hipLaunchKernelGGL(kvec_plain_kernel, dim3((unsigned)((d->M + 63) / 64), chunks), dim3(256), 0, st, (const bf16_t*)d->A, d->lda, d->a_kmajor,
+                           (long)d->M, d->K, (const bf16_t*)d->kvec, slabs, kchunk);
+        if (chunks > 1)
+            hipLaunchKernelGGL(kvec_reduce_kernel, dim3((unsigned)((d->M + 255) / 256)), dim3(256), 0, st, (const float*)slabs, chunks, (long)d->M, d->kvec_out);
+    }
     if (d->row_scale && !t_row_scaled) {
         // the kernel that ran has no row factor in its epilogue: one more pass over C
         const long total = (long)d->M * d->N;
@@ -2055,9 +2094,9 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
         // at most 32 slabs, each at least 8 k-tiles deep, as many as the workspace holds
         const long slab_bytes = (long)a.M * a.N * 4;
         // with a vector product: up to 32 slabs of M floats at the end of the workspace
-        const long kv_bytes = a.kvec ? 32L * a.M * 4 : 0;
+        const long kv_bytes = a.kvec_out ? 32L * a.M * 4 : 0;
         const long ws_bytes = d->workspace_bytes > kv_bytes ? (d->workspace_bytes - kv_bytes) & ~15L : 0;
-        float* kv_slabs = a.kvec ? (float*)((char*)d->workspace + ws_bytes) : nullptr;
+        float* kv_slabs = a.kvec_out ? (float*)((char*)d->workspace + ws_bytes) : nullptr;
         long maxsp = nkt / 8 < 32 ? nkt / 8 : 32;
         if (ws_bytes / slab_bytes < maxsp) maxsp = ws_bytes / slab_bytes;
         // 256x256 tiles (one workgroup per CU) when some split gives (nearly) every CU one; else 256x128 / 128x128 tiles
@@ -2078,7 +2117,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             GemmArgs b = a;
             b.C = d->workspace; b.ldc = a.N; b.out_dtype = CAPDEC_F32; b.accumulate = 0;
             b.split_k = (int)split; b.split_stride = slab;
-            if (a.kvec) { b.kvec_out = kv_slabs; b.kvec_out_stride = a.M; }
+            if (a.kvec_out) { b.kvec_out = kv_slabs; b.kvec_out_stride = a.M; }
             b.fast_epi = (a.N % 4) == 0 && ((slab * 4) % 16) == 0 && aligned16(d->workspace) ? 4 : 0;
             int rc = launch_gemm<EPI_STD>(b, d->in_dtype, (hipStream_t)stream);
             if (rc) return rc;
@@ -2087,7 +2126,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
                 hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (bf16_t*)a.C, a.ldc, a.accumulate, d->row_scale);
             else
                 hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)d->workspace, (int)split, slab, a.M, a.N, (float*)a.C, a.ldc, a.accumulate, d->row_scale);
-            if (a.kvec && t_kvec_done)
+            if (a.kvec_out && t_kvec_done)
                 hipLaunchKernelGGL(kvec_reduce_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                                    (const float*)kv_slabs, (int)split, (long)a.M, d->kvec_out);
             CAPDEC_LAUNCH_CHECK();

@@ -587,53 +587,57 @@ class DecoderEngine:
             ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
         dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
         delta = self.buf("delta", (B * H * S,), torch.float32, dev)
-        # in_proj's bias gradient = column sums of dQKV: the attention backward leaves them per 16-row tile (bf16 kernels),
-        # so that only those partial rows are summed, not the rows of dQKV
-        csq = cskv = None
-        if cdt == torch.bfloat16:
-            qr, kr = ops.attn_bwd_colsum_rows(B, S, S - q_start, hd)
-            csq = self.buf("attn_colsum_q", (qr, d), torch.float32, dev)
-            cskv = self.buf("attn_colsum_kv", (kr, 2 * d), torch.float32, dev)
         with self._span("block_attn_bwd"):
             ops.attn_bwd_packed(sv["qkv"], sv["attn_o"], sv["lse"], dattn, dqkv, delta, B, H, S, hd, q_start=q_start, nq=S - q_start,
-                                mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5,
-                                colsum_q=csq, colsum_kv=cskv)
+                                mask_mode=_MASKS[self.opt.mask_mode], prefix_len=self.prefix_len, drop=k_attn, dq_scale=hd ** -0.5)
         gin_w, gin_b = G("self_attn.in_proj_weight"), G("self_attn.in_proj_bias")
         h1 = sv["h1"]
-        # in_proj's bias gradient (column sums of dQKV, a pure read stream) goes with its weight gradient: nothing
-        # downstream waits for it, and next to the dgrad product on the main stream it costs next to nothing
+        # in_proj's bias gradient = column sums of dQKV = dQKV^T . 1: one more column of its weight-gradient product, formed by
+        # that product's kernel (bf16; in f32 a pass of its own)
+        lp = cdt == torch.bfloat16
         csws_side = self.buf("colsum_ws_side", (csws.numel(),), torch.uint8, dev)
 
-        def in_proj_bias_grad(ws):
-            if csq is not None:
-                ops.colsum(csq, gin_b[:d], ws)
-                ops.colsum(cskv, gin_b[d:], ws)
-            elif q_start == 0:
+        def wgrad_q(ws):
+            ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=ws,
+                     kvec_out=gin_b[:d] if lp else None)
+
+        def wgrad_kv(ws):
+            ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=ws,
+                     kvec_out=gin_b[d:] if lp else None)
+
+        def wgrad_all(ws):
+            ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=ws, kvec_out=gin_b if lp else None)
+
+        def bias_grad_f32(ws):
+            if lp:
+                return
+            if q_start == 0:
                 ops.colsum(dqkv, gin_b, ws)
             else:
                 ops.colsum(dqkv[r0:, :d], gin_b[:d], ws)
                 ops.colsum(dqkv[:, d:], gin_b[d:], ws)
+
         split_streams = bool(sv.get("folded"))
         if split_streams:
-            # nothing is left for the main stream but to wait for these gradients: it takes the column sums and the
-            # query rows' product (with a split-K workspace of its own) while the side stream runs the large product
+            # nothing is left for the main stream but to wait for these gradients: it takes the query rows' product (with a
+            # split-K workspace of its own) while the side stream runs the large one
             if q_start == 0:
-                self._on_side_stream(lambda: ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
-                in_proj_bias_grad(csws)
+                self._on_side_stream(lambda: wgrad_all(skws))
+                bias_grad_f32(csws)
             else:
-                self._on_side_stream(lambda: ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
-                skws_q = self.buf("splitk_ws_q", (32 * d * d * 4,), torch.uint8, dev)
-                in_proj_bias_grad(csws)
-                ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws_q)
+                self._on_side_stream(lambda: wgrad_kv(skws))
+                skws_q = self.buf("splitk_ws_q", (33 * d * d * 4,), torch.uint8, dev)
+                bias_grad_f32(csws)
+                wgrad_q(skws_q)
         elif q_start == 0:
             def in_proj_grads():
-                in_proj_bias_grad(csws_side)
-                ops.gemm(dqkv, h1, gin_w, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
+                bias_grad_f32(csws_side)
+                wgrad_all(skws)
         else:
             def in_proj_grads():
-                in_proj_bias_grad(csws_side)
-                ops.gemm(dqkv[r0:, :d], h1[r0:], gin_w[:d], M=d, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws)
-                ops.gemm(dqkv[:, d:], h1, gin_w[d:], M=2 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws)
+                bias_grad_f32(csws_side)
+                wgrad_q(skws)
+                wgrad_kv(skws)
         if not split_streams:
             self._on_side_stream(in_proj_grads)
         # dh1 is needed even when the block input is data: LayerNorm-1's affine gradients come from it

@@ -201,9 +201,9 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
     if row_scale is not None:
         assert row_scale.dtype == torch.float32 and row_scale.numel() == M and row_scale.is_contiguous()
         d.row_scale = ptr(row_scale)
-    if kvec is not None:
-        assert kvec.dtype == A.dtype == torch.bfloat16 and kvec.numel() == K and kvec.is_contiguous()
-        assert kvec_out.dtype == torch.float32 and kvec_out.numel() >= M and kvec_out.is_contiguous()
+    if kvec_out is not None:               # kvec None: a vector of ones
+        assert kvec is None or (kvec.dtype == torch.bfloat16 and kvec.numel() == K and kvec.is_contiguous())
+        assert A.dtype == torch.bfloat16 and kvec_out.dtype == torch.float32 and kvec_out.numel() >= M and kvec_out.is_contiguous()
         d.kvec, d.kvec_out = ptr(kvec), ptr(kvec_out)
     check(_lib.load().capdec_gemm_bias_act(C.byref(d), _st()), "capdec_gemm_bias_act")
     return Cout

@@ -165,9 +165,10 @@ typedef struct {
     void* workspace; long workspace_bytes;
     /* optional [M] f32: C = diag(row_scale) (A B); plain products only (no epilogue term, no accumulate) */
     const float* row_scale;
-    /* optional, plain bf16 products only: kvec [K] bf16, kvec_out [M] f32 (OVERWRITTEN) = sum_k A(m,k) * kvec[k], one more
-     * column of the product formed on the way where the kernel allows (the vocabulary bias gradient next to the weight
-     * gradient).  With a split-K workspace, 32*M*4 bytes at its end are used for this. */
+    /* optional, plain bf16 products only: kvec [K] bf16 (NULL with kvec_out given: a vector of ones), kvec_out [M] f32
+     * (OVERWRITTEN) = sum_k A(m,k) * kvec[k], one more column of the product formed on the way where the kernel allows
+     * (the bias gradient of a Linear next to its weight gradient: with ones, the column sums of the reduction-major
+     * operand).  With a workspace, 32*M*4 bytes at its end are used for this. */
     const void* kvec; float* kvec_out;
 } capdec_gemm_desc;
 

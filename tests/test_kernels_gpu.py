@@ -352,6 +352,11 @@ def test_gemm_vector_column(M, N, K, with_ws):
     out2 = torch.full((M,), float("nan"), device=DEV)
     ops.gemm(A, B, C1, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws, kvec=v, kvec_out=out2)
     assert torch.equal(out2, out)                                       # fixed summation order
+    # no vector: ones, i.e. the column sums of the reduction-major operand
+    out3 = torch.full((M,), float("nan"), device=DEV)
+    ops.gemm(A, B, C1, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws, kvec_out=out3)
+    assert torch.equal(C1, C0)
+    close(out3, A.float().sum(0), 2e-3, "column sums as a vector column")
 
 
 def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
