@@ -476,7 +476,7 @@ class DecoderEngine:
             rowscale_lp = self.buf("ce_rowscale_lp", (Mh,), cdt, dev)
             with self._span("ce_bwd_prepare"):
                 ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B, L, lse, rowref, gscale, hs, rowscale, rowscale_lp)
-            if self.opt.ce_bias_in_wgrad:
+            if self.opt.ce_bias_in_wgrad and Mh <= 8192:        # the kernel keeps the row factors of its k range (all Mh rows) in LDS
                 # the bias gradient is one more column of the weight-gradient product (numerators^T . rowscale): formed by that
                 # product's kernel on the way instead of by a pass over the numerators
                 with self._span("head_wgrad_slab"):

@@ -22,8 +22,8 @@ LAUNCHES = {
     "ce_bias_grad": ("wcolsum_bf16_kernel", None),          # only with --no-ce-bias-in-wgrad
     "logits_ce_bwd_slab": ("gemm_bf16_dma_kernel<false, false, 2, 2, 2, 8, 3>", None),
     # two launches: the whole rounds of 256x256 tiles (170 x 3) and the split-K tail (27 x 3 tiles, 3 slabs)
-    "head_wgrad_slab": [("gemm_bf16_pipe_kernel<true, true, 0, 8, true>", 170 * 3 * 256), ("gemm_bf16_pipe_kernel<true, true, 0, 8, true>", 27 * 3 * 3 * 256)],
-    "head_dgrad_slab": ("gemm_bf16_pipe_kernel<false, true, 0, 8, false>", 32 * 3 * 8 * 256),
+    "head_wgrad_slab": [("gemm_bf16_pipe_kernel<true, true, 0, 8, 1>", 170 * 3 * 256), ("gemm_bf16_pipe_kernel<true, true, 0, 8, 1>", 27 * 3 * 3 * 256)],
+    "head_dgrad_slab": ("gemm_bf16_pipe_kernel<false, true, 0, 8, 0>", 32 * 3 * 8 * 256),
 }
 
 
