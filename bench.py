@@ -64,6 +64,8 @@ def parse():
                     help="softmax numerators kept per 64-column slot and turned into d(logits) by a pass of its own (A/B)")
     ap.add_argument("--no-ce-bias-in-wgrad", action="store_true",
                     help="vocabulary bias gradient by a pass over the numerators instead of as a column of the weight-gradient product (A/B)")
+    ap.add_argument("--dgrad-transposed-weights", action="store_true",
+                    help="data gradients of the vocabulary matrix, linear2 and out_proj on transposed weight copies (row-major second operand; A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
@@ -299,6 +301,8 @@ def main():
             opts.ce_row_reference = False
         if args.no_ce_bias_in_wgrad:
             opts.ce_bias_in_wgrad = False
+        if args.dgrad_transposed_weights:
+            opts.dgrad_transposed_weights = True
         if args.no_wgrad_stream:
             opts.wgrad_stream = False
         torch.manual_seed(42)                                           # config.py:27,41

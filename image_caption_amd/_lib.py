@@ -151,6 +151,7 @@ SIGNATURES = {
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "capdec_transpose_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
     "capdec_colsum_workspace": (c_long, [c_long, c_int]),
     "capdec_dropout_bwd_cast": (c_int, [c_void_p, c_long, c_int, Dropout, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_colsum": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_long, c_void_p]),

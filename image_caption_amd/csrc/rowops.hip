@@ -744,6 +744,61 @@ extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dt
     return CAPDEC_OK;
 }
 
+// ------------------------------------------------------------------ transposed copy of a bf16 matrix
+// dst[c, r] = src[r, c]: 64x64 tiles through LDS (row pitch 66 elements: neighbouring rows of a column fall on different
+// banks).  PAIR: both leading dimensions even and both bases 4-byte aligned -- two elements per access on both sides.
+namespace {
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <bool PAIR>
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* src, long lds_, bf16_t* dst, long ldd, int rows, int cols) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 column pairs x 8 rows per pass
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = r0 + ty + 8 * p, c = c0 + 2 * tx;
+        bf16_t a = (bf16_t)0.f, b = (bf16_t)0.f;
+        if (r < rows) {
+            if (PAIR && c + 1 < cols) {
+                const bf16x2_t v = *reinterpret_cast<const bf16x2_t*>(src + (long)r * lds_ + c);
+                a = v[0]; b = v[1];
+            } else {
+                if (c < cols) a = src[(long)r * lds_ + c];
+                if (c + 1 < cols) b = src[(long)r * lds_ + c + 1];
+            }
+        }
+        tile[ty + 8 * p][2 * tx] = a; tile[ty + 8 * p][2 * tx + 1] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int c = c0 + ty + 8 * p, r = r0 + 2 * tx;              // output row c, output columns r, r + 1
+        if (c < cols) {
+            const bf16_t a = tile[2 * tx][ty + 8 * p], b = tile[2 * tx + 1][ty + 8 * p];
+            if (PAIR && r + 1 < rows) {
+                bf16x2_t v; v[0] = a; v[1] = b;
+                *reinterpret_cast<bf16x2_t*>(dst + (long)c * ldd + r) = v;
+            } else {
+                if (r < rows) dst[(long)c * ldd + r] = a;
+                if (r + 1 < rows) dst[(long)c * ldd + r + 1] = b;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int capdec_transpose_bf16(const void* src, long ld_src, long rows, long cols, void* dst, long ld_dst, void* stream) {
+    CAPDEC_CHECK(src && dst && rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows, "transpose: bad arguments");
+    CAPDEC_CHECK(rows < (1L << 31) && cols < (1L << 31) && (rows + 63) / 64 < 65536, "transpose: too large");
+    if (rows == 0 || cols == 0) return CAPDEC_OK;
+    const bool pair = (ld_src & 1) == 0 && (ld_dst & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0;
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    if (pair) hipLaunchKernelGGL(transpose_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, (int)rows, (int)cols);
+    else hipLaunchKernelGGL(transpose_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, (int)rows, (int)cols);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
 extern "C" long capdec_colsum_workspace(long M, int N) {
     const int rows = colsum_stripe_rows(M);
     return ((M + rows - 1) / rows) * (long)N * 4 + 16;

@@ -55,6 +55,8 @@ class EngineOptions:
     dl_budget_bytes: int = 16 << 30               # cap on the d(logits) slab buffer (the whole vocabulary fits up to batch 5000 per GPU)
     wgrad_stream: bool = True                     # the block's weight-gradient products run on a second HIP stream
     keep_softmax_numerators: bool = True          # forward keeps exp(z - slot max) when d(logits) fits: no recomputation in backward
+    dgrad_transposed_weights: bool = False        # data gradients whose weight is read along `out` (vocabulary, linear2, out_proj) take a
+                                                  # transposed bf16 copy made once per step: a row-major second operand (measured slower in the step)
     ce_bias_in_wgrad: bool = True                 # ... and the vocabulary bias gradient taken as one more column of the weight-gradient product
     ce_row_reference: bool = True                 # ... kept against one reference per row (the label's logit), so that d(logits) is a
                                                   # row factor times the numerators and the backward products read them as they are
@@ -455,6 +457,18 @@ class DecoderEngine:
         dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev) if want_grads else None
         by_row = from_probs and self.opt.ce_row_reference and cdt == torch.bfloat16 and d % 32 == 0 and d >= 256
         self.last_by_row = by_row
+        head_wt = head_wt_ready = None
+        if by_row and self.opt.dgrad_transposed_weights:
+            # W^T for the data gradient, made beside the forward product (the second stream is idle until the backward)
+            kk_t = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V
+            wt_shape = (d, (kk_t + 7) // 8 * 8)
+            fresh = ("head_w_t", wt_shape, cdt) not in self._bufs
+            head_wt = self.buf("head_w_t", wt_shape, cdt, dev)
+            if fresh:
+                head_wt[:, V:].zero_()                    # the columns of the padding rows: never written again
+            self._on_side_stream(lambda: ops.transpose(W.head_w, head_wt[:, :V]))
+            head_wt_ready = torch.cuda.Event()
+            head_wt_ready.record(self._side if (self.opt.wgrad_stream and self._side is not None) else torch.cuda.current_stream())
         with self._span("logits_ce_fwd"):
             if by_row:
                 rowref = self.buf("ce_rowref", (Mh,), torch.float32, dev)
@@ -492,7 +506,11 @@ class DecoderEngine:
                 on_grad_ready(HEAD_W, 0, V)
             kk = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V
             with self._span("head_dgrad_slab"):
-                ops.gemm(dl, W.head_w, dH, M=Mh, N=d, K=kk, b_kmajor=True, workspace=hws, row_scale=rowscale)
+                if head_wt is not None:
+                    torch.cuda.current_stream().wait_event(head_wt_ready)
+                    ops.gemm(dl, head_wt, dH, M=Mh, N=d, K=kk, workspace=hws, row_scale=rowscale)
+                else:
+                    ops.gemm(dl, W.head_w, dH, M=Mh, N=d, K=kk, b_kmajor=True, workspace=hws, row_scale=rowscale)
         for v0 in (() if by_row else range(0, V, slab)):
             nv = min(slab, V - v0)
             ld = (nv + 127) // 128 * 128
@@ -561,12 +579,17 @@ class DecoderEngine:
         self._on_side_stream(lambda: ops.gemm(g2, sv["a1"], G("linear2.weight"), M=d, N=ff, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dz1 = self.buf("dz1", (Mt, ff), cdt, dev)
         gcws = self.buf("gate_colsum_ws", ((Mt + 63) // 64 * ff * 4,), torch.uint8, dev)     # one partial row of bias sums per 64 rows
+        tw = self.opt.dgrad_transposed_weights and cdt == torch.bfloat16
+        w2, w2_km = w["linear2.weight"], True
+        if tw:
+            w2 = ops.transpose(w["linear2.weight"], self.buf("linear2_w_t", (ff, d), cdt, dev))
+            w2_km = False
         with self._span("block_mlp_dgrad"):
             if self.opt.activation == "relu":
-                ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
+                ops.gemm(g2, w2, dz1, M=Mt, N=ff, K=d, b_kmajor=w2_km, gate=sv["a1"], gate_mode=GATE_RELU_OUT,
                          gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
             else:
-                ops.gemm(g2, w["linear2.weight"], dz1, M=Mt, N=ff, K=d, b_kmajor=True, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
+                ops.gemm(g2, w2, dz1, M=Mt, N=ff, K=d, b_kmajor=w2_km, gate=sv["z1"], gate_mode=GATE_GELU_PRE,
                          gate_drop=k_h, colsum=G("linear1.bias"), workspace=gcws)
         self._on_side_stream(lambda: ops.gemm(dz1, sv["h2"], G("linear1.weight"), M=ff, N=d, K=Mt, a_kmajor=True, b_kmajor=True, workspace=skws))
         dh2 = self.buf("dh", (Mt, d), cdt, dev)
@@ -584,7 +607,11 @@ class DecoderEngine:
                                               b_kmajor=True, workspace=skws))
         dattn = self.buf("dattn", (M, d), cdt, dev)
         with self._span("block_out_proj_dgrad"):
-            ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
+            if tw:
+                wot = ops.transpose(w["self_attn.out_proj.weight"], self.buf("out_proj_w_t", (d, d), cdt, dev))
+                ops.gemm(g1, wot, dattn[r0:], M=Mt, N=d, K=d)
+            else:
+                ops.gemm(g1, w["self_attn.out_proj.weight"], dattn[r0:], M=Mt, N=d, K=d, b_kmajor=True)
         dqkv = self.buf("dqkv", (M, 3 * d), cdt, dev)
         delta = self.buf("delta", (B * H * S,), torch.float32, dev)
         with self._span("block_attn_bwd"):

@@ -360,6 +360,15 @@ def cast(src, dst):
     return dst
 
 
+def transpose(src, dst):
+    """dst[c, r] = src[r, c] (bf16, 2-D, unit inner stride on both sides)."""
+    require_cuda(src, dst)
+    rows, cols = src.shape
+    assert src.dtype == dst.dtype == torch.bfloat16 and dst.shape == (cols, rows) and src.stride(1) == 1 and dst.stride(1) == 1
+    check(_lib.load().capdec_transpose_bf16(ptr(src), src.stride(0), rows, cols, ptr(dst), dst.stride(0), _st()), "capdec_transpose_bf16")
+    return dst
+
+
 def colsum_workspace(M, N) -> int:
     return _lib.load().capdec_colsum_workspace(M, N)
 

@@ -303,6 +303,10 @@ int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dt
 /* ------------------------------------------------------------------ element-wise helpers */
 /* dst = cast(src) for n elements */
 int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* dst[c, r] = src[r, c] for a bf16 matrix [rows, cols] (leading dimensions in elements).  The data gradients of
+ * decoder.py:189 read a weight [out, in] along `out`; on a transposed copy made once per step the second operand of
+ * those products is row-major, which the product kernels read at twice the LDS rate of the transposing read. */
+int capdec_transpose_bf16(const void* src, long ld_src, long rows, long cols, void* dst, long ld_dst, void* stream);
 /* Column sums are computed in two deterministic stages (row stripes, then a fixed-order fold) and
  * need a scratch buffer of capdec_colsum_workspace(M,N) bytes. */
 long capdec_colsum_workspace(long M, int N);

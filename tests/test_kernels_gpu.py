@@ -1002,3 +1002,16 @@ def test_ln_fold_pair_matches_autograd(dtype, tol, N, K, M):
     close(G, Wp.grad, 2e-5, "weight gradient")
     close(dgamma, g.grad, 2e-5, "dgamma")
     close(dbeta, b.grad, 2e-5, "dbeta")
+
+
+@pytest.mark.parametrize("rows,cols", [(768, 768), (50260, 768), (2048, 768), (67, 130), (1, 5)])
+def test_transpose_bf16(rows, cols):
+    src = rnd(rows, cols, dtype=torch.bfloat16, seed=95)
+    dst = torch.full((cols, (rows + 7) // 8 * 8), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.transpose(src, dst[:, :rows])
+    assert torch.equal(dst[:, :rows], src.t())
+    if dst.shape[1] > rows:
+        assert bool(torch.isnan(dst[:, rows:].float()).all())          # nothing written past the matrix
+    odd = torch.full((cols, rows + 1), float("nan"), device=DEV, dtype=torch.bfloat16)      # odd leading dimension: element-wise path
+    ops.transpose(src, odd[:, :rows])
+    assert torch.equal(odd[:, :rows], src.t())
