@@ -98,13 +98,19 @@ def test_tiny_golden_logits_loss_grads(dtype, slab, keep):
     check_grads(model, ref_grads, dtype)
 
 
-@pytest.mark.parametrize("dtype,slab", [(F32, 0), (BF16, 0), (BF16, 8192)])    # slab 8192: the recomputing backward
-def test_default_b8_golden(dtype, slab):
+@pytest.mark.parametrize("dtype,slab,opt", [
+    (F32, 0, {}), (BF16, 0, {}),
+    (BF16, 8192, {}),                                   # the recomputing backward
+    (BF16, 0, {"ce_row_reference": False}),             # numerators per 64-column slot, d(logits) made by a pass of its own
+    (BF16, 0, {"ce_bias_in_wgrad": False}),             # vocabulary bias gradient by weighted column sums
+    (BF16, 0, {"dgrad_transposed_weights": True}),      # data gradients on transposed weight copies
+])
+def test_default_b8_golden(dtype, slab, opt):
     g = golden("default_b8.npz")
     sh = DEFAULT_B8
     sd = helpers.make_state_dict(sh, seed=303)
     img, sos, cap, labels = helpers.make_embeddings(sh, seed=404)
-    model = make_model(sh, sd, dtype, vocab_slab=slab)
+    model = make_model(sh, sd, dtype, vocab_slab=slab, **opt)
     x = ref_cpu.concat_prefix(img, sos, cap).to(DEV)
     with torch.no_grad():
         logits = model(x, x)
