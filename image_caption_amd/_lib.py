@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 MASK_NONE, MASK_REFERENCE, MASK_PREFIX_CAUSAL = 0, 1, 2
 GATE_NONE, GATE_RELU_OUT, GATE_GELU_PRE = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 1
+#define CAPDEC_ABI_VERSION 2
 
 enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1 };
 enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_RELU = 1, CAPDEC_ACT_GELU = 2 };
