@@ -1592,7 +1592,16 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
             f32x4 q[FIN_UNROLL];
 #pragma unroll
             for (int u = 0; u < FIN_UNROLL; ++u)
-                if (sl + u * FIN_GROUPS < np) q[u] = part4[(long)(sl + u * FIN_GROUPS) * M + m];
+                if (sl + u * FIN_GROUPS < np) {
+                    if constexpr (REF) {
+                        // 8-byte records {packed maximum, sum}: the argmax is the slot's first column + 63 - (the low 6 bits)
+                        const f32x2 r2 = reinterpret_cast<const f32x2*>(part4)[(long)(sl + u * FIN_GROUPS) * M + m];
+                        const int arg = (sl + u * FIN_GROUPS) * 64 + 63 - (int)(__float_as_uint(r2[0]) & 63u);
+                        q[u] = f32x4{r2[0], r2[1], -INFINITY, __int_as_float(arg)};
+                    } else {
+                        q[u] = part4[(long)(sl + u * FIN_GROUPS) * M + m];
+                    }
+                }
 #pragma unroll
             for (int u = 0; u < FIN_UNROLL; ++u)
                 if (sl + u * FIN_GROUPS < np) {

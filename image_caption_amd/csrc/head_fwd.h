@@ -22,8 +22,9 @@ struct HeadFwdArgs {
     unsigned drop_thr, drop_k0, drop_k1; float drop_scale;      // thr 0: off; element index m * N + n
     // mode 2 (C is the f32 output [M, ldc], given through Cf; C itself unused): y = residual + dropout(z + bias)
     float* Cf; const float* residual; long ldr;
-    // mode 3: mode 0 with C required and everything taken against a given reference per row: the partials hold
-    // {max_n (z - rowref), sum_n exp(z - rowref), -inf, argmax}, C holds exp(z - rowref)
+    // mode 3: mode 0 with C required and everything taken against a given reference per row: the partials are 8-byte
+    // records [np slots][M rows] of {max_n (z - rowref) with 63 - (column in the slot) in its low 6 bits, sum_n exp(z - rowref)}
+    // in the same buffer; C holds exp(z - rowref)
     const float* rowref;
 };
 

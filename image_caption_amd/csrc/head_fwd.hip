@@ -353,7 +353,13 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                 for (int t = 0; t < 16; ++t) { v[t] = __builtin_amdgcn_exp2f(fmaf(v[t], LOG2E, nref)); sum += v[t]; }
                 sum = quad_sum(sum);
                 if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
-                {
+                if constexpr (MODE == 3) {
+                    // 8-byte records {packed maximum, sum}: the column inside the slot rides in the maximum's low bits
+                    const u32x2_t rec = {__float_as_uint(pm), __float_as_uint(sum)};
+                    const __amdgpu_buffer_rsrc_t prs = rsrc_at((const char*)p.part4 + ((long)slot * p.M + mb) * 8, 0xFFFFFFF0L);
+                    const unsigned off = (q == 0 && row_ok && slot_ok) ? (unsigned)(r16 * 8) : 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_buffer_store_b64(rec, prs, off, 0, 0);
+                } else {
                     const int arg = nw + 63 - (int)(__float_as_uint(pm) & 63u);
                     const f32x4 rec = {pm, sum, -INFINITY, __int_as_float(arg)};
                     const __amdgpu_buffer_rsrc_t prs = rsrc_at((const char*)(p.part4 + ((long)slot * p.M + mb)), 0xFFFFFFF0L);
