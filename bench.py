@@ -66,6 +66,8 @@ def parse():
                     help="vocabulary bias gradient by a pass over the numerators instead of as a column of the weight-gradient product (A/B)")
     ap.add_argument("--dgrad-transposed-weights", action="store_true",
                     help="data gradients of the vocabulary matrix, linear2 and out_proj on transposed weight copies (row-major second operand; A/B)")
+    ap.add_argument("--no-head-k-panels", action="store_true",
+                    help="the vocabulary product reads its operands row-major (A/B of the k-panel images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
@@ -305,6 +307,8 @@ def main():
             opts.dgrad_transposed_weights = True
         if args.no_wgrad_stream:
             opts.wgrad_stream = False
+        if args.no_head_k_panels:
+            opts.head_k_panels = False
         torch.manual_seed(42)                                           # config.py:27,41
         model = TransformerDecoder(768, 8, 6, 2048, 0.1, 50260, n_blocks=n_blocks, options=opts).to(dev)
         model.train()                                                   # decoder.py:144: dropout active

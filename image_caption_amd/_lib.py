@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 MASK_NONE, MASK_REFERENCE, MASK_PREFIX_CAUSAL = 0, 1, 2
 GATE_NONE, GATE_RELU_OUT, GATE_GELU_PRE = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 
@@ -100,7 +100,12 @@ class DecodeDesc(C.Structure):
         ("max_len", c_int), ("t", c_int), ("s_new", c_int),
         ("eos_id", C.c_int64), ("pad_id", C.c_int64),
         ("workspace", c_void_p), ("workspace_bytes", c_long),
+        ("head_w_panels", c_void_p), ("head_w_panel_rows", c_long),
     ]
+
+
+class KPanels(C.Structure):
+    _fields_ = [("a", c_void_p), ("a_rows", c_long), ("b", c_void_p), ("b_rows", c_long)]
 
 
 # name -> (restype, argtypes); every symbol include/capdec.h declares
@@ -135,7 +140,8 @@ SIGNATURES = {
     "capdec_logits_ce_workspace": (c_long, [c_long, c_int]),
     "capdec_logits_ce_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_long, c_void_p, c_long, c_void_p]),
+                                     c_void_p, c_long, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),
+    "capdec_pack_kpanels": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_from_probs": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_float,
                                                 c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
@@ -144,12 +150,12 @@ SIGNATURES = {
     "capdec_logits_ce_bwd_workspace": (c_long, [c_long, c_int]),
     "capdec_logits_ce_fwd_ref": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
+                                         c_void_p, c_long, c_void_p, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_ref_prepare": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int,
                                                  c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "capdec_colsum_weighted": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
-                                     c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+                                     c_void_p, c_void_p, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),
     "capdec_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
     "capdec_transpose_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
     "capdec_colsum_workspace": (c_long, [c_long, c_int]),

@@ -2234,6 +2234,16 @@ int head_fwd_choice(const GemmArgs& a, int dtype, HeadFwdArgs& ha) {
     if (g_gemm_mode != 0) return -1;
     return (long)a.M * a.N >= (1L << 24) ? g_head_fwd_geometry : -1;
 }
+// k-panel images of the operands: only the persistent kernel reads them (every other kernel takes the row-major operands)
+bool panels_ok(const capdec_kpanels* k, long M, long V) {
+    if (!k) return true;
+    return (!k->a || (aligned16(k->a) && k->a_rows >= M)) && (!k->b || (aligned16(k->b) && k->b_rows >= V));
+}
+void set_panels(HeadFwdArgs& ha, const capdec_kpanels* k) {
+    if (!k) return;
+    ha.Ap = (const bf16_t*)k->a; ha.a_rows = k->a_rows;
+    ha.Bp = (const bf16_t*)k->b; ha.b_rows = k->b_rows;
+}
 }  // namespace
 
 // diagnostic hook (not part of the declared ABI): default geometry of the persistent forward kernel
@@ -2243,9 +2253,10 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
                                     long M, int V, int d, long ldh, long ldw,
                                     const int64_t* labels, int B, int L,
                                     float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
-                                    void* probs, long ld_probs,
+                                    void* probs, long ld_probs, const capdec_kpanels* panels,
                                     void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct, "logits_ce_fwd: null pointer");
+    CAPDEC_CHECK(panels_ok(panels, M, V), "logits_ce_fwd: k-panel images must be 16-byte aligned and hold at least M / V rows per panel");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(!probs || (ld_probs >= V && (ld_probs % 8) == 0 && ld_probs <= (long)((V + BN - 1) / BN) * BN && aligned16(probs)),
                  "logits_ce_fwd: ld_probs (%ld) must be a multiple of 8 in [V, roundup128(V)] and probs 16-byte aligned", ld_probs);
@@ -2266,6 +2277,7 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     const int geo = head_fwd_choice(a, dtype, ha);
     int rc;
     if (geo >= 0) {
+        set_panels(ha, panels);
         rc = head_fwd_launch(ha, geo, st);
         dot = LabelDot{(const bf16_t*)h, (const bf16_t*)W, bias, ldh, ldw, d};     // that kernel leaves the label's logit to the finalize pass
     } else {
@@ -2284,9 +2296,10 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
                                         long M, int V, int d, long ldh, long ldw,
                                         const int64_t* labels, int B, int L,
                                         float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
-                                        void* probs, long ld_probs, float* rowref,
+                                        void* probs, long ld_probs, float* rowref, const capdec_kpanels* panels,
                                         void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct && probs && rowref, "logits_ce_fwd_ref: null pointer");
+    CAPDEC_CHECK(panels_ok(panels, M, V), "logits_ce_fwd_ref: k-panel images must be 16-byte aligned and hold at least M / V rows per panel");
     CAPDEC_CHECK(dtype == CAPDEC_BF16, "logits_ce_fwd_ref: bf16 operands only");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd_ref: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(ld_probs >= V && (ld_probs % 8) == 0 && ld_probs <= (long)((V + BN - 1) / BN) * BN && aligned16(probs),
@@ -2302,6 +2315,7 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
     ha.A = (const bf16_t*)h; ha.B = (const bf16_t*)W; ha.bias = bias; ha.C = (bf16_t*)probs;
     ha.lda = ldh; ha.ldb = ldw; ha.ldc = ld_probs; ha.M = (int)M; ha.N = V; ha.K = d; ha.store_cols = (int)ld_probs;
     ha.part4 = ws.part4; ha.np = ws.np; ha.mode = 3; ha.rowref = rowref;
+    set_panels(ha, panels);
     CAPDEC_CHECK(head_fwd_supported(ha), "logits_ce_fwd_ref: shape not supported (d %% 32 == 0, d >= 256, 16-byte aligned rows)");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(label_logit_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)h, ldh, (const bf16_t*)W, ldw, bias, d,
@@ -2336,9 +2350,10 @@ extern "C" int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long
 
 extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
                                     long M, int V, int d, long ldh, long ldw,
-                                    int64_t* out_ids, float* margin,
+                                    int64_t* out_ids, float* margin, const capdec_kpanels* panels,
                                     void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && out_ids, "logits_argmax: null pointer");
+    CAPDEC_CHECK(panels_ok(panels, M, V), "logits_argmax: k-panel images must be 16-byte aligned and hold at least M / V rows per panel");
     CAPDEC_CHECK(M < (1L << 31), "logits_argmax: M too large");
     CeWs ws;
     if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {
@@ -2353,6 +2368,7 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     hipStream_t st = (hipStream_t)stream;
     HeadFwdArgs ha;
     const int geo = margin ? -1 : head_fwd_choice(a, dtype, ha);      // the second maximum (margins) is the generic epilogue's
+    if (geo >= 0) set_panels(ha, panels);
     const int rc = geo >= 0 ? head_fwd_launch(ha, geo, st) : launch_gemm<EPI_CE_FWD>(a, dtype, st);
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel<false>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,

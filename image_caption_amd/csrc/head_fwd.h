@@ -26,6 +26,12 @@ struct HeadFwdArgs {
     // records [np slots][M rows] of {max_n (z - rowref) with 63 - (column in the slot) in its low 6 bits, sum_n exp(z - rowref)}
     // in the same buffer; C holds exp(z - rowref)
     const float* rowref;
+    // k-panel images of the operands (NULL: read A / B as given): [K / 32 panels][rows][32] bf16, so that the 16 rows x 64
+    // bytes one LDS-DMA instruction fetches are 1 KiB of consecutive bytes -- whole 128-byte lines instead of half lines
+    const bf16_t* Ap; long a_rows;       // rows per panel of A's image (>= M)
+    const bf16_t* Bp; long b_rows;       // rows per panel of B's image (>= N)
+    // filled by head_fwd_launch: bytes from one k-step's columns to the next, and by how much a view shrinks per k-step
+    long kstepA, kstepB; int remdecA, remdecB;
 };
 
 // geometry 0: 256x128 tiles, 4 waves, two workgroups per CU; 1: 256x256 tiles, 8 waves, one workgroup per CU

@@ -302,6 +302,32 @@ __global__ void cast_kernel(const TS* s, TD* d, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = from_f32<TD>(to_f32<TS>(s[i]));
 }
 
+// k-panel image of a matrix: panels[k / 32][r][k % 32] = bf16(src[r, k]).  A block takes 16 rows x 256 columns: a
+// thread reads 8 consecutive elements of a row (the 32 lanes of a row 512 or 1024 consecutive bytes) and writes them as one
+// 16-byte chunk; a wave's store covers 8 panels x 128 consecutive bytes (2 rows).  Optionally the plain bf16 cast as well.
+template <typename TS>
+__global__ __launch_bounds__(256) void pack_kpanels_kernel(const TS* src, long ld_src, long rows, int K, bf16_t* panels, long panel_rows,
+                                                            bf16_t* rowmajor, long ld_rm) {
+    const int c = threadIdx.x & 31;                        // 8-element chunk inside the block's 256 columns
+    const int k = blockIdx.x * 256 + c * 8;
+    if (k >= K) return;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const long r = (long)blockIdx.y * 16 + pass * 8 + (threadIdx.x >> 5);
+        if (r >= rows) continue;
+        bf16x8 v;
+        if constexpr (sizeof(TS) == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * ld_src + k), b = *reinterpret_cast<const f32x4*>(src + r * ld_src + k + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (bf16_t)a[e]; v[4 + e] = (bf16_t)b[e]; }
+        } else {
+            v = *reinterpret_cast<const bf16x8*>(src + r * ld_src + k);
+        }
+        *reinterpret_cast<bf16x8*>(panels + ((long)(k >> 5) * panel_rows + r) * 32 + (k & 31)) = v;
+        if (rowmajor) *reinterpret_cast<bf16x8*>(rowmajor + r * ld_rm + k) = v;
+    }
+}
+
 __global__ void dropout_mask_kernel(uint32_t thr, uint32_t k0, uint32_t k1, long n, float* out) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -740,6 +766,31 @@ extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dt
     else if (src_dtype == CAPDEC_BF16 && dst_dtype == CAPDEC_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
     else if (src_dtype == CAPDEC_F32 && dst_dtype == CAPDEC_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
     else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    CAPDEC_LAUNCH_CHECK();
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_pack_kpanels(const void* src, int src_dtype, long rows, int K, long ld_src,
+                                   void* panels, long panel_rows, void* rowmajor, long ld_rm, void* stream) {
+    CAPDEC_CHECK(src && panels, "pack_kpanels: null pointer");
+    CAPDEC_CHECK(src_dtype == CAPDEC_F32 || src_dtype == CAPDEC_BF16, "pack_kpanels: bad dtype");
+    const long per16 = src_dtype == CAPDEC_F32 ? 4 : 8;
+    CAPDEC_CHECK(rows >= 0 && K > 0 && (K % 32) == 0 && ld_src >= K && (ld_src % per16) == 0 && panel_rows >= rows && aligned16(src) && aligned16(panels),
+                 "pack_kpanels: K (%d) must be a multiple of 32, rows of src 16-byte aligned, panel_rows (%ld) >= rows (%ld)", K, panel_rows, rows);
+    CAPDEC_CHECK(!rowmajor || (ld_rm >= K && (ld_rm % 8) == 0 && aligned16(rowmajor)), "pack_kpanels: rows of the row-major copy must be 16-byte aligned");
+    if (rows == 0) return CAPDEC_OK;
+    CAPDEC_CHECK((rows + 15) / 16 <= 65535L * 16, "pack_kpanels: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    // the grid's y extent is limited to 65535: rows beyond that go to further launches
+    for (long r0 = 0; r0 < rows; r0 += 65535L * 16) {
+        const long nr = rows - r0 < 65535L * 16 ? rows - r0 : 65535L * 16;
+        dim3 g((unsigned)((K + 255) / 256), (unsigned)((nr + 15) / 16)), b(256);
+        bf16_t* rm = rowmajor ? (bf16_t*)rowmajor + r0 * ld_rm : nullptr;
+        if (src_dtype == CAPDEC_F32)
+            hipLaunchKernelGGL(pack_kpanels_kernel<float>, g, b, 0, st, (const float*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm);
+        else
+            hipLaunchKernelGGL(pack_kpanels_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm);
+    }
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -114,7 +114,16 @@ class TransformerDecoder(nn.Module):
             if i == 0:
                 b[IN_PROJ_MASTER] = named[block_key(0, "self_attn.in_proj_weight", self.n_blocks)].detach()
             blocks.append(b)
-        return _Weights(blocks, mat(HEAD_W), named[HEAD_B].detach())
+        head_w = mat(HEAD_W)
+        panels = None
+        if cdt == torch.bfloat16 and self.options.head_k_panels and head_w.shape[1] % 32 == 0:
+            # the k-panel image of the vocabulary matrix is remade when its shadow is
+            p = named[HEAD_W]
+            ver, panels = self._shadow.get("head.k_panels", (None, None))
+            if panels is None or ver != (p._version, p.data_ptr()) or panels.device != p.device:
+                panels = ops.pack_kpanels(head_w, torch.empty(ops.kpanel_shape(*head_w.shape), dtype=cdt, device=p.device))
+                self._shadow["head.k_panels"] = ((p._version, p.data_ptr()), panels)
+        return _Weights(blocks, head_w, named[HEAD_B].detach(), head_w_panels=panels)
 
     def _param_keys(self):
         keys = [HEAD_W, HEAD_B]
@@ -311,6 +320,7 @@ class CaptionTrainer:
         # one launch over the flat buffer on a single GPU; with several, one launch per all-reduce bucket, so
         # that the update of the vocabulary matrix overlaps the reduction of the last bucket
         self.reducer.drain(adam)
+        st.refresh_head_panels()
         return out
 
     @torch.no_grad()

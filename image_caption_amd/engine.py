@@ -63,6 +63,8 @@ class EngineOptions:
     composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     fold_norm1: bool = True                       # training without input gradient: block 0's norm1 affine is folded into in_proj
+    head_k_panels: bool = True                    # the vocabulary product reads k-panel images ([d/32][rows][32]) of h and of the vocabulary
+                                                  # matrix: whole 128-byte lines per load instead of half lines (bit-identical results)
     dropout_seed: int = 42
 
 
@@ -116,6 +118,10 @@ class ParamStore:
         self.v = torch.zeros(off, dtype=torch.float32, device=device) if with_optimizer_state else None
         self.shadow = torch.zeros(off, dtype=compute_dtype, device=device) if compute_dtype != torch.float32 else self.w
         self.offsets = {k: (o, s) for k, s, o in self.layout}
+        # k-panel image of the vocabulary matrix's shadow (what the persistent logits kernel reads), kept current by
+        # refresh_head_panels() after every change of the parameters
+        self.head_panels = (torch.zeros(ops.kpanel_shape(V, d), dtype=torch.bfloat16, device=device)
+                            if compute_dtype == torch.bfloat16 and d % 32 == 0 else None)
 
     def view(self, buf: torch.Tensor, key: str) -> torch.Tensor:
         o, shape = self.offsets[key]
@@ -128,6 +134,11 @@ class ParamStore:
     def refresh_shadow(self):
         if self.shadow is not self.w:
             ops.cast(self.w, self.shadow)
+        self.refresh_head_panels()
+
+    def refresh_head_panels(self):
+        if self.head_panels is not None:
+            ops.pack_kpanels(self.compute(HEAD_W), self.head_panels)
 
     def load(self, state: Dict[str, torch.Tensor]):
         for key, shape, _ in self.layout:
@@ -177,11 +188,12 @@ class _Weights:
     """Per-call view of the tensors the kernels read: matrices in compute dtype,
     biases / LayerNorm affine in f32."""
 
-    def __init__(self, blocks, head_w, head_b, head_pad_rows: int = 0):
+    def __init__(self, blocks, head_w, head_b, head_pad_rows: int = 0, head_w_panels=None):
         self.blocks = blocks
         self.head_w = head_w
         self.head_b = head_b
         self.head_pad_rows = head_pad_rows      # zero rows that physically follow head_w's last row
+        self.head_w_panels = head_w_panels      # k-panel image of head_w ([d/32, V, 32] bf16, ops.pack_kpanels) or None
 
 
 def weights_from_store(store: ParamStore) -> _Weights:
@@ -195,7 +207,7 @@ def weights_from_store(store: ParamStore) -> _Weights:
         if i == 0:
             b[IN_PROJ_MASTER] = store.param(block_key(0, "self_attn.in_proj_weight", geo.n_blocks))
         blocks.append(b)
-    return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows)
+    return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows, store.head_panels)
 
 
 def _seqfirst_addressable(t: torch.Tensor) -> bool:
@@ -435,7 +447,14 @@ class DecoderEngine:
         Mh = L * B
         x_tail = x[x.shape[0] - Mh:]                           # scored rows (l*B + b)
         h = self.buf("head_in", (Mh, d), cdt, dev)
-        ops.cast(x_tail, h) if cdt != torch.float32 else h.copy_(x_tail)
+        w_panels = W.head_w_panels if (self.opt.head_k_panels and cdt == torch.bfloat16) else None
+        h_panels = None
+        if w_panels is not None:
+            # the cast of the scored rows also leaves their k-panel image
+            h_panels = self.buf("head_in_panels", ops.kpanel_shape(Mh, d), cdt, dev)
+            ops.pack_kpanels(x_tail, h_panels, rowmajor=h)
+        else:
+            ops.cast(x_tail, h) if cdt != torch.float32 else h.copy_(x_tail)
         ws = self.buf("ce_ws", (ops.logits_ce_workspace(Mh, V),), torch.uint8, dev)
         lse = self.buf("ce_lse", (Mh,), torch.float32, dev)
         amax = self.buf("ce_argmax", (Mh,), torch.int32, dev)
@@ -472,9 +491,11 @@ class DecoderEngine:
         with self._span("logits_ce_fwd"):
             if by_row:
                 rowref = self.buf("ce_rowref", (Mh,), torch.float32, dev)
-                ops.logits_ce_fwd_ref(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, dl, rowref)
+                ops.logits_ce_fwd_ref(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, dl, rowref,
+                                      h_panels=h_panels, w_panels=w_panels)
             else:
-                ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, probs=dl if from_probs else None)
+                ops.logits_ce_fwd(h, W.head_w, W.head_b, labels, B, L, lse, amax, loss_sum, correct, ws, probs=dl if from_probs else None,
+                                  h_panels=h_panels, w_panels=w_panels)
         if not want_grads:
             return loss_sum, correct, Mh
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
@@ -822,11 +843,15 @@ class DecoderEngine:
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
         if emb.dtype != torch.float32 or not emb.is_contiguous():
             raise ValueError("the token-embedding table must be a contiguous float32 [vocab, d_model] tensor")
+        w_panels = W.head_w_panels if (self.opt.head_k_panels and cdt == torch.bfloat16) else None
+        if w_panels is None and self.opt.head_k_panels and cdt == torch.bfloat16 and d % 32 == 0 and W.head_w.stride(1) == 1:
+            # the weights stay as they are for the whole loop: one image serves every token
+            w_panels = ops.pack_kpanels(W.head_w, self.buf("gen_head_panels", ops.kpanel_shape(V, d), cdt, dev))
         if self.timer is not None or not self.opt.composed_decode_step:
             # per-kernel event brackets are wanted: issue the step's launches one by one (the same kernels,
             # in the same order, as capdec_decode_step)
             self._decode_loop_by_op(W, caches, x_last, emb, pos, ids, done, out, margins, max_len, S0, smax, eos_id, pad_id,
-                                    stop_check_every)
+                                    stop_check_every, w_panels)
             return (out, margins) if return_margins else out
         mg = self.buf("gen_margin", (B,), torch.float32, dev)
         # the residual stream of the newest row lives in one buffer that every step reads and rewrites
@@ -861,6 +886,8 @@ class DecoderEngine:
         dd.margin = mg.data_ptr() if return_margins else None       # unasked for, the head runs without the second maximum
         dd.max_len, dd.eos_id, dd.pad_id = max_len, eos_id, pad_id
         dd.workspace, dd.workspace_bytes = ws.data_ptr(), wsb
+        if w_panels is not None:
+            dd.head_w_panels, dd.head_w_panel_rows = w_panels.data_ptr(), w_panels.shape[1]
         stream = _lib.stream_ptr()
         for t in range(max_len):
             dd.t, dd.s_new = t, S0 + t                               # s_new: index of the row appended after token t
@@ -875,7 +902,7 @@ class DecoderEngine:
         return (out, margins) if return_margins else out
 
     def _decode_loop_by_op(self, W, caches, x_last, emb, pos, ids, done, out, margins, max_len, S0, smax, eos_id, pad_id,
-                           stop_check_every):
+                           stop_check_every, w_panels=None):
         geo, cdt = self.geo, self.cdt
         d, ff, H, hd, V, nb = geo.d_model, geo.dim_feedforward, geo.nhead, geo.hd, geo.vocab_size, geo.n_blocks
         B, dev, scale = ids.shape[0], ids.device, geo.hd ** -0.5
@@ -894,7 +921,7 @@ class DecoderEngine:
         for t in range(max_len):
             ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
             with self._span("logits_argmax"):
-                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg if return_margins else None, ws)
+                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg if return_margins else None, ws, w_panels=w_panels)
             if return_margins:
                 margins[:, t].copy_(mg)
             ops.greedy_update(ids, done, out, t, eos_id, pad_id)

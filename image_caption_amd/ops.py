@@ -279,8 +279,37 @@ def logits_ce_workspace(M, V) -> int:
     return _lib.load().capdec_logits_ce_workspace(M, V)
 
 
-def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs=None):
-    """probs (optional, [M, ld] of h's dtype): receives the softmax numerators for logits_ce_bwd_from_probs."""
+def kpanel_shape(rows: int, K: int):
+    """Shape of the k-panel image of a [rows, K] matrix: [K / 32 panels, rows, 32]."""
+    assert K % 32 == 0
+    return (K // 32, rows, 32)
+
+
+def pack_kpanels(src, panels, rowmajor=None):
+    """panels[k // 32, r, k % 32] = bf16(src[r, k]); rowmajor (optional, bf16 [rows, K]) receives the plain cast as well."""
+    require_cuda(src, panels, rowmajor)
+    rows, K = src.shape
+    assert panels.dtype == torch.bfloat16 and panels.is_contiguous() and panels.shape[0] == K // 32 and panels.shape[2] == 32 and panels.shape[1] >= rows
+    assert src.stride(1) == 1 and (rowmajor is None or (rowmajor.dtype == torch.bfloat16 and rowmajor.shape == src.shape and rowmajor.stride(1) == 1))
+    check(_lib.load().capdec_pack_kpanels(ptr(src), dtype_code(src), rows, K, _ld(src), ptr(panels), panels.shape[1],
+                                          ptr(rowmajor), _ld(rowmajor) if rowmajor is not None else 0, _st()), "capdec_pack_kpanels")
+    return panels
+
+
+def _kpanels(h_panels, w_panels, M, V, d):
+    """The capdec_kpanels argument (None when no image is given); the images are [d / 32, rows, 32] bf16 tensors."""
+    if h_panels is None and w_panels is None:
+        return None
+    for t, n in ((h_panels, M), (w_panels, V)):
+        assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[0] == d // 32 and t.shape[1] >= n and t.shape[2] == 32)
+    require_cuda(h_panels, w_panels)
+    return _lib.KPanels(ptr(h_panels), h_panels.shape[1] if h_panels is not None else 0,
+                        ptr(w_panels), w_panels.shape[1] if w_panels is not None else 0)
+
+
+def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs=None, h_panels=None, w_panels=None):
+    """probs (optional, [M, ld] of h's dtype): receives the softmax numerators for logits_ce_bwd_from_probs.
+    h_panels / w_panels (optional): k-panel images of h / W (pack_kpanels)."""
     require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace, probs)
     M, d = h.shape
     V = W.shape[0]
@@ -288,11 +317,11 @@ def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, work
     assert probs is None or (probs.dtype == h.dtype and probs.shape[0] == M)
     check(_lib.load().capdec_logits_ce_fwd(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
                                            ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct),
-                                           ptr(probs), _ld(probs) if probs is not None else 0, ptr(workspace),
-                                           workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
+                                           ptr(probs), _ld(probs) if probs is not None else 0, _kpanels(h_panels, w_panels, M, V, d),
+                                           ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
 
 
-def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs, rowref):
+def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs, rowref, h_panels=None, w_panels=None):
     """logits_ce_fwd with the numerators kept against one reference per row (rowref [M] f32, written here): probs [M, ld] bf16
     = exp(z - rowref).  The backward starts from logits_ce_bwd_ref_prepare."""
     require_cuda(h, W, bias, labels, lse, argmax, loss_sum, correct, workspace, probs, rowref)
@@ -303,7 +332,7 @@ def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, 
     assert rowref.dtype == torch.float32 and rowref.numel() == M and rowref.is_contiguous()
     check(_lib.load().capdec_logits_ce_fwd_ref(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
                                                ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct),
-                                               ptr(probs), _ld(probs), ptr(rowref), ptr(workspace),
+                                               ptr(probs), _ld(probs), ptr(rowref), _kpanels(h_panels, w_panels, M, V, d), ptr(workspace),
                                                workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd_ref")
 
 
@@ -345,12 +374,12 @@ def logits_ce_bwd_slab(h, W, bias, labels, B, L, lse, gscale, v0, nv, dl, dbias,
           "capdec_logits_ce_bwd_slab")
 
 
-def logits_argmax(h, W, bias, out_ids, margin, workspace):
+def logits_argmax(h, W, bias, out_ids, margin, workspace, h_panels=None, w_panels=None):
     require_cuda(h, W, bias, out_ids, margin, workspace)
     M, d = h.shape
     V = W.shape[0]
     check(_lib.load().capdec_logits_argmax(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(out_ids), ptr(margin),
-                                           ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "capdec_logits_argmax")
+                                           _kpanels(h_panels, w_panels, M, V, d), ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "capdec_logits_argmax")
 
 
 def cast(src, dst):

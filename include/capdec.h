@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 2
+#define CAPDEC_ABI_VERSION 3
 
 enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1 };
 enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_RELU = 1, CAPDEC_ACT_GELU = 2 };
@@ -237,11 +237,28 @@ int capdec_attn_decode(const void* q, const void* kv_cache, void* o, int dtype,
  * zero); together with the workspace's per-slot maxima they let capdec_logits_ce_bwd_from_probs
  * form d(logits) without a second product over the vocabulary. */
 long capdec_logits_ce_workspace(long M, int V);
+
+/* k-panel images of the two operands of the vocabulary product (decoder.py:66: h [M,d] and output_projection.weight
+ * [V,d]), optional everywhere they appear (NULL pointer, or NULL members: the row-major operands are read instead).
+ * An image holds the same bf16 values as the matrix, laid out [d / 32 panels][rows][32]: the 32 reduction elements of a
+ * row that one step of the product consumes are 64 consecutive bytes, and consecutive rows follow each other, so the
+ * product's loads fetch whole 128-byte lines (row-major rows of 2*d bytes give it half lines).  Results are bit-identical
+ * either way; made by capdec_pack_kpanels.  a / b: image of h / of W; a_rows >= M, b_rows >= V: rows per panel. */
+typedef struct {
+    const void* a; long a_rows;
+    const void* b; long b_rows;
+} capdec_kpanels;
+/* panels[k / 32][r][k % 32] = bf16(src[r, k]) for r < rows, k < K (K % 32 == 0; src f32 or bf16 [rows, ld_src], rows
+ * 16-byte aligned; panels 16-byte aligned, panel_rows >= rows rows per panel -- rows rows..panel_rows-1 are not written).
+ * rowmajor (optional, bf16 [rows, ld_rm]) receives the plain cast of src in the same pass (capdec_cast). */
+int capdec_pack_kpanels(const void* src, int src_dtype, long rows, int K, long ld_src,
+                        void* panels, long panel_rows, void* rowmajor, long ld_rm, void* stream);
+
 int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
                          long M, int V, int d, long ldh, long ldw,
                          const int64_t* labels, int B, int L,
                          float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
-                         void* probs, long ld_probs,
+                         void* probs, long ld_probs, const capdec_kpanels* panels,
                          void* workspace, long workspace_bytes, void* stream);
 
 /* Backward of the mean loss w.r.t. logits (autograd of decoder.py:140,180,189) from what the
@@ -280,7 +297,7 @@ int capdec_logits_ce_fwd_ref(const void* h, const void* W, const float* bias, in
                              long M, int V, int d, long ldh, long ldw,
                              const int64_t* labels, int B, int L,
                              float* lse, int32_t* argmax, float* loss_sum, int32_t* correct,
-                             void* probs, long ld_probs, float* rowref,
+                             void* probs, long ld_probs, float* rowref, const capdec_kpanels* panels,
                              void* workspace, long workspace_bytes, void* stream);
 /* Backward of decoder.py:172 from those numerators: with g[m] = gscale * exp(rowref[m] - lse[m]),
  * d(logits)[m,v] = g[m] * probs'[m,v], probs' = probs except probs'[m,label] = probs[m,label] - exp(lse[m] - rowref[m])
@@ -297,7 +314,7 @@ int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
  * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
 int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
                          long M, int V, int d, long ldh, long ldw,
-                         int64_t* out_ids, float* margin,
+                         int64_t* out_ids, float* margin, const capdec_kpanels* panels,
                          void* workspace, long workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ element-wise helpers */
@@ -383,6 +400,7 @@ typedef struct {
     int max_len, t, s_new;
     int64_t eos_id, pad_id;
     void* workspace; long workspace_bytes;
+    const void* head_w_panels; long head_w_panel_rows;   /* optional k-panel image of head_w (capdec_kpanels.b), or NULL */
 } capdec_decode_desc;
 
 long capdec_decode_step_workspace(int B, int d_model, int dim_ff, int vocab, int dtype);

@@ -248,6 +248,69 @@ def test_persistent_logits_ce_forward(gemm_mode, mode, B_, L, V, d, with_bias):
     assert int(ids.min()) >= 0 and int(ids.max()) < V
 
 
+@pytest.mark.parametrize("src_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,K,extra", [(1, 32, 0), (37, 288, 3), (8192, 768, 0), (50260, 768, 44), (300, 2048, 0)])
+def test_pack_kpanels(src_dtype, rows, K, extra):
+    """k-panel image [K/32][rows][32] of a matrix (with rows to spare per panel, which must stay untouched) and the
+    row-major cast the same pass can leave; source with a leading dimension larger than K."""
+    ld = K + (8 if rows < 1000 else 0)
+    src = rnd(rows, ld, dtype=src_dtype, seed=301)[:, :K]
+    panels = torch.full(ops.kpanel_shape(rows + extra, K), 7.0, device=DEV, dtype=torch.bfloat16)
+    rm = torch.full((rows, K), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.pack_kpanels(src, panels, rowmajor=rm)
+    want = src.to(torch.bfloat16)
+    assert torch.equal(rm, want)
+    assert torch.equal(panels[:, :rows], want.view(rows, K // 32, 32).permute(1, 0, 2))
+    assert extra == 0 or bool((panels[:, rows:] == 7.0).all())
+    panels2 = torch.empty_like(panels)
+    ops.pack_kpanels(src, panels2)
+    assert torch.equal(panels2[:, :rows], panels[:, :rows])
+
+
+@pytest.mark.parametrize("mode", [8, 9])
+@pytest.mark.parametrize("B_,L,V,d,extra", [(5, 8, 1111, 256, 0), (37, 9, 2000, 288, 5), (1, 3, 130, 256, 1), (64, 9, 50260, 768, 0)])
+def test_logits_ce_forward_from_k_panels(gemm_mode, mode, B_, L, V, d, extra):
+    """The persistent forward reading k-panel images of h, of W or of both gives bit for bit what it gives on the row-major
+    operands: every entry point that takes them (training forward in both forms, greedy argmax)."""
+    M = B_ * L
+    h = rnd(M, d, dtype=torch.bfloat16, seed=271)
+    w = rnd(V, d, dtype=torch.bfloat16, scale=2.0 / math.sqrt(d), seed=272)
+    b = rnd(V, seed=273)
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(274)).to(DEV)
+    # images with rows to spare per panel, filled with NaN: nothing past the matrix may be read as data
+    hp = torch.full(ops.kpanel_shape(M + extra, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    wp = torch.full(ops.kpanel_shape(V + extra, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.pack_kpanels(h, hp)
+    ops.pack_kpanels(w, wp)
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    Vp = (V + 127) // 128 * 128
+
+    def run(kind, hpan, wpan):
+        lse, amax = torch.full((M,), float("nan"), device=DEV), torch.full((M,), -1, dtype=torch.int32, device=DEV)
+        ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+        dl = torch.full((M, Vp), float("nan"), device=DEV, dtype=torch.bfloat16)
+        rowref = torch.full((M,), float("nan"), device=DEV)
+        ids = torch.full((M,), -1, dtype=torch.int64, device=DEV)
+        gemm_mode(mode)
+        if kind == 0:
+            ops.logits_ce_fwd(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, probs=dl, h_panels=hpan, w_panels=wpan)
+        elif kind == 1:
+            ops.logits_ce_fwd_ref(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, dl, rowref, h_panels=hpan, w_panels=wpan)
+        else:
+            ops.logits_argmax(h, w, b, ids, None, ws, h_panels=hpan, w_panels=wpan)
+        gemm_mode(0)
+        return [ids] if kind == 2 else [lse, amax, ls, cr, dl] + ([rowref] if kind == 1 else [])
+
+    for kind in (0, 1, 2):
+        base = run(kind, None, None)
+        assert not bool(torch.isnan(base[0].float()).any()) and int(base[0 if kind == 2 else 1].min()) >= 0
+        for hpan, wpan in ((hp, None), (None, wp), (hp, wp)):
+            got = run(kind, hpan, wpan)
+            for x, y in zip(got, base):
+                assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else torch.nan_to_num(x),
+                                   y.view(torch.int16) if y.dtype == torch.bfloat16 else torch.nan_to_num(y))
+
+
 @pytest.mark.parametrize("mode", [8, 9])
 @pytest.mark.parametrize("B_,L,V,d,with_bias,hot_rows", [
     (5, 8, 1111, 256, True, 0),
