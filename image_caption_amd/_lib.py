@@ -104,6 +104,10 @@ class DecodeDesc(C.Structure):
     ]
 
 
+class AdamPanels(C.Structure):
+    _fields_ = [("panels", c_void_p), ("first", c_long), ("rows", c_long), ("K", c_int), ("panel_rows", c_long)]
+
+
 class KPanels(C.Structure):
     _fields_ = [("a", c_void_p), ("a_rows", c_long), ("b", c_void_p), ("b_rows", c_long)]
 
@@ -164,7 +168,7 @@ SIGNATURES = {
     "capdec_colsum_static": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p]),
     "capdec_embed_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "capdec_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
-                                 c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+                                 c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, C.POINTER(AdamPanels), c_void_p]),
     "capdec_greedy_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_int64, C.c_int64, c_void_p]),
     "capdec_decode_step_workspace": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "capdec_decode_step": (c_int, [C.POINTER(DecodeDesc), c_void_p]),

@@ -59,6 +59,7 @@ struct GemmArgs {
     unsigned long long* stamps;      // diagnostic: 8 clock stamps per workgroup, NULL in normal use
     // one more column of a plain product: kvec_out[y * kvec_out_stride + m] = sum over the workgroup's k range of A(m,k) * kvec[k]
     const bf16_t* kvec; float* kvec_out; long kvec_out_stride;
+    long a_panel;                    // > 0: A's stored matrix is a column-panel image with this many rows per panel (pipelined 256x256 kernel only)
 };
 
 // ------------------------------------------------------------------ tile order
@@ -126,6 +127,7 @@ struct OperandView {
     long remaining;       // elements addressable from base
     long ld;
     int rows_left;        // valid rows (non-reduction index) from the panel start
+    long panel = 0;       // 0: a plain matrix; R > 0: the stored matrix [R][cols] lies as a column-panel image [cols / 32][R][32]
 };
 struct ThreadPlan {
     unsigned voff;        // byte offset of chunk 0 inside a k-tile (0xFFFFFFFF: never in range)
@@ -837,14 +839,19 @@ __device__ __forceinline__ unsigned dma_src_offset(const OperandView& v, int pie
         const int sub = piece >> 3, pp = piece & 7;
         const int krow = 4 * pp + (lane >> 4), pc = lane & 15;
         const int col = sub * 128 + (pc ^ (kswz(krow) << 1)) * 8;
+        if (v.panel) return col < v.rows_left ? (unsigned)((((long)(col >> 5) * v.panel + krow) * 32 + (col & 31)) * 2) : 0xFFFFFFFFu;
         return col < v.rows_left ? (unsigned)(((long)krow * v.ld + col) * 2) : 0xFFFFFFFFu;
     }
 }
 
+// elements between the images of k and k + 1 (k a multiple of 32 for a row-major panel image, whose panels are `panel` rows of 32)
+template <bool TR>
+__device__ __forceinline__ long k_unit(const OperandView& v) { return TR ? (v.panel ? 32L : v.ld) : (v.panel ? v.panel : 1L); }
+
 // buffer descriptor of an operand's k-tile starting at k0 (reads past the operand's end return 0)
 template <bool TR>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const OperandView& v, int k0) {
-    const long adv = TR ? (long)k0 * v.ld : (long)k0;
+    const long adv = (long)k0 * k_unit<TR>(v);
     const long rem = (v.remaining - adv) * 2;
     const int hi = (int)(rem >> 32);
     const unsigned lo = (unsigned)rem;
@@ -1090,6 +1097,14 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
     if (B_TR) { vb.base = (const bf16_t*)p.B + n0; vb.remaining = (long)p.K * p.ldb - n0; }
     else      { vb.base = (const bf16_t*)p.B + (long)n0 * p.ldb; vb.remaining = (long)(p.N - n0) * p.ldb; }
     vb.ld = p.ldb; vb.rows_left = p.N - n0;
+    if (p.a_panel) {
+        // A's stored matrix ([M][K], or [K][M] when reduction-major) as a column-panel image: [cols / 32][a_panel rows][32]
+        va.panel = p.a_panel;
+        const long total = (long)(((A_TR ? p.M : p.K) + 31) / 32) * p.a_panel * 32;
+        const long first = A_TR ? (long)(m0 >> 5) * p.a_panel * 32 : (long)m0 * 32;
+        va.base = (const bf16_t*)p.A + first; va.remaining = total - first;
+        if (!A_TR) va.ld = 32;
+    }
     unsigned offa[PA], offb[PB];
 #pragma unroll
     for (int j = 0; j < PA; ++j) offa[j] = dma_src_offset<A_TR>(va, 4 * j + wave, lane);
@@ -1186,7 +1201,7 @@ __global__ __launch_bounds__(256, (PipeGeo<TJ>::WG_PER_CU)) void gemm_bf16_pipe_
     int slot = 0;                            // ring slot of stage kt
     // the refill of step kt reads k-tile kt0 + kt + NST: its start and the bytes addressable from there advance by a
     // constant per step, which keeps the descriptor arithmetic inside the main loop to a few scalar instructions
-    const long stepA = (A_TR ? (long)DBK * va.ld : (long)DBK) * 2, stepB = (B_TR ? (long)DBK * vb.ld : (long)DBK) * 2;      // bytes
+    const long stepA = DBK * k_unit<A_TR>(va) * 2, stepB = DBK * k_unit<B_TR>(vb) * 2;      // bytes
     const char* refA = (const char*)va.base + (long)(kt0 + NST) * stepA;
     const char* refB = (const char*)vb.base + (long)(kt0 + NST) * stepB;
     long remA = va.remaining * 2 - (long)(kt0 + NST) * stepA, remB = vb.remaining * 2 - (long)(kt0 + NST) * stepB;
@@ -1374,6 +1389,7 @@ unsigned long long* g_stamps = nullptr;
 thread_local bool t_kvec_done = false;      // the last launch_gemm formed A . kvec next to the product
 constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
+long g_dbg_a_panel = 0;  // diagnostic: the next 256x256 pipelined launches read A as a column-panel image with this many rows per panel
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 pipelined 256x256, 7 pipelined 256x128)
 
 template <int EPI>
@@ -1469,6 +1485,8 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)(wide_tiles), split), dim3(256), PipeGeo<8>::LDS + (MODE == 1 ? KVEC_BYTES : 0), st, a); \
         t_kvec_done = true;                                                                            \
     } while (0)
+        if (g_dbg_a_panel && kern == KERN_QUAD) a.a_panel = g_dbg_a_panel;
+        CAPDEC_CHECK(!a.a_panel || kern == KERN_QUAD, "gemm: a column-panel image of A is read by the pipelined 256x256 kernel only");
         if (kern == KERN_TALLP) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_PIPE_LAUNCH(true, true, EPI_STD, 4, big_tiles);
@@ -1984,6 +2002,7 @@ extern "C" int capdecdbg_occupy(int wgs, int lds_bytes, long microseconds, void*
 // diagnostic hook (not part of the declared ABI): clock stamps of every workgroup of the next GEMM launches
 extern "C" void capdecdbg_gemm_stamps(void* device_buffer) { g_stamps = (unsigned long long*)device_buffer; }
 extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
+extern "C" void capdecdbg_gemm_a_panel(long rows) { g_dbg_a_panel = rows; }
 extern "C" void capdecdbg_gemm_extra_lds(int bytes) { g_extra_lds = bytes > 0 ? bytes : 0; }
 
 // ==================================================================== C ABI

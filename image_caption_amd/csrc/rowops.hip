@@ -469,7 +469,10 @@ __global__ void embed_rows_kernel(const float* table, const int64_t* ids, long n
 // torch.optim.Adam (coupled L2): g += wd*w; m,v EMA; w -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n,
                                                     float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps,
-                                                    float wd, float gscale, bf16_t* wb) {
+                                                    float wd, float gscale, bf16_t* wb,
+                                                    bf16_t* panels, long pfirst, long pn, int pK, long prows) {
+    // panels: k-panel image [pK / 32][prows][32] of the row-major matrix that occupies elements pfirst .. pfirst + pn - 1
+    // (pfirst a multiple of 4, pK a multiple of 32: a thread's 4 elements never straddle a row or a panel)
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -490,6 +493,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
             __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + i));
             __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
             if (wb) store4<bf16_t>(wb + i, wv);
+            if (panels && i >= pfirst && i - pfirst < pn) {
+                const unsigned idx = (unsigned)(i - pfirst), r = idx / (unsigned)pK, k = idx - r * (unsigned)pK;
+                store4<bf16_t>(panels + ((long)(k >> 5) * prows + r) * 32 + (k & 31), wv);
+            }
         } else {
             for (long j = i; j < n; ++j) {
                 const float gg = g[j] * gscale + wd * w[j];
@@ -497,6 +504,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
                 v[j] = beta2 * v[j] + (1.f - beta2) * gg * gg;
                 w[j] -= lr_over_bc1 * (m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + eps));
                 if (wb) wb[j] = (bf16_t)w[j];
+                if (panels && j >= pfirst && j - pfirst < pn) {
+                    const unsigned idx = (unsigned)(j - pfirst), r = idx / (unsigned)pK, k = idx - r * (unsigned)pK;
+                    panels[((long)(k >> 5) * prows + r) * 32 + (k & 31)] = (bf16_t)w[j];
+                }
             }
         }
     }
@@ -986,13 +997,23 @@ extern "C" int capdec_embed_rows(const float* table, const int64_t* ids, long n,
 
 extern "C" int capdec_adam_step(float* w, const float* g, float* m, float* v, long n, int step,
                                 float lr, float beta1, float beta2, float eps, float weight_decay,
-                                float grad_scale, void* w_bf16, void* stream) {
+                                float grad_scale, void* w_bf16, const capdec_adam_panels* panels, void* stream) {
     CAPDEC_CHECK(w && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+    bf16_t* pp = nullptr;
+    long pfirst = 0, pn = 0, prows = 0;
+    int pK = 0;
+    if (panels && panels->panels) {
+        CAPDEC_CHECK(panels->rows > 0 && panels->K > 0 && (panels->K % 32) == 0 && panels->panel_rows >= panels->rows && (panels->first % 4) == 0 &&
+                     panels->rows * (long)panels->K < (1L << 32) && aligned16(panels->panels),
+                     "adam_step: the matrix behind a k-panel image must start at a multiple of 4 elements, K a multiple of 32, panel_rows >= rows");
+        pp = (bf16_t*)panels->panels; pfirst = panels->first; pn = panels->rows * (long)panels->K; pK = panels->K; prows = panels->panel_rows;
+    }
     CAPDEC_CHECK(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
     if (n == 0) return CAPDEC_OK;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       w, g, m, v, n, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)w_bf16);
+                       w, g, m, v, n, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)w_bf16,
+                       pp, pfirst, pn, pK, prows);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -312,15 +312,18 @@ class CaptionTrainer:
                                  on_grad_ready=self.reducer.on_grad_ready)
         model._shadow.clear()      # module-mode shadows of the matrices are stale after this update
         st = self.store
+        head_first, head_shape = st.offsets[HEAD_W]
+        head_rows = head_shape[0]
 
         def adam(lo, hi):          # bucket boundaries are 64-element aligned: every slice stays 16-byte aligned
             ops.adam_step(st.w[lo:hi], st.g[lo:hi], st.m[lo:hi], st.v[lo:hi], self.step_count, self.lr, self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, grad_scale=1.0 / self.reducer.world_size,
-                          w_bf16=st.shadow[lo:hi] if st.shadow is not st.w else None)
+                          w_bf16=st.shadow[lo:hi] if st.shadow is not st.w else None,
+                          # the vocabulary matrix's k-panel image is refreshed by the same pass
+                          panels=st.head_panels, panel_first=head_first - lo, panel_rows=head_rows)
         # one launch over the flat buffer on a single GPU; with several, one launch per all-reduce bucket, so
         # that the update of the vocabulary matrix overlaps the reduction of the last bucket
         self.reducer.drain(adam)
-        st.refresh_head_panels()
         return out
 
     @torch.no_grad()

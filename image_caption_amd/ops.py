@@ -444,10 +444,16 @@ def embed_rows(table, ids, out, pos_row=None):
     check(_lib.load().capdec_embed_rows(ptr(table), ptr(ids), n, d, ptr(pos_row), ptr(out), _st()), "capdec_embed_rows")
 
 
-def adam_step(w, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, w_bf16=None):
-    require_cuda(w, g, m, v, w_bf16)
+def adam_step(w, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, w_bf16=None, panels=None, panel_first=0, panel_rows=0):
+    """panels (optional, [K/32, >= panel_rows, 32] bf16): k-panel image of the row-major [panel_rows, K] matrix that starts
+    panel_first elements after w[0] (may be negative when w is a slice of the flat buffer), refreshed by the same pass."""
+    require_cuda(w, g, m, v, w_bf16, panels)
+    pd = None
+    if panels is not None:
+        assert panels.dtype == torch.bfloat16 and panels.is_contiguous() and panels.shape[2] == 32 and panels.shape[1] >= panel_rows
+        pd = _lib.AdamPanels(ptr(panels), panel_first, panel_rows, panels.shape[0] * 32, panels.shape[1])
     check(_lib.load().capdec_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), step, lr, beta1, beta2, eps, weight_decay,
-                                       grad_scale, ptr(w_bf16), _st()), "capdec_adam_step")
+                                       grad_scale, ptr(w_bf16), pd, _st()), "capdec_adam_step")
 
 
 def greedy_update(ids, done, out, t, eos_id, pad_id):

@@ -352,12 +352,22 @@ int capdec_colsum_static(const void* x, int dtype, long M, int N, long ldx, floa
 int capdec_embed_rows(const float* table, const int64_t* ids, long n, int d, const float* pos_row,
                       float* out, void* stream);
 
+/* A row-major matrix [rows, K] inside the flat buffer whose k-panel image (capdec_kpanels.b: the vocabulary matrix) the
+ * update keeps current: it occupies elements first .. first + rows*K - 1 counted from `w` (first may be negative or the
+ * matrix may extend past n when the call covers a slice of the buffer: only the elements inside the call are written). */
+typedef struct {
+    void* panels;            /* [K / 32][panel_rows][32] bf16, or NULL */
+    long first;              /* a multiple of 4 */
+    long rows; int K;        /* K a multiple of 32 */
+    long panel_rows;         /* >= rows */
+} capdec_adam_panels;
 /* torch.optim.Adam(lr, betas, eps, weight_decay) with coupled L2 (decoder.py:135-139,190)
  * over a flat f32 parameter buffer; optionally refreshes a bf16 shadow copy used by
- * the MFMA kernels.  grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+ * the MFMA kernels and (panels, may be NULL) the k-panel image of one matrix in it.
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int capdec_adam_step(float* w, const float* g, float* m, float* v, long n, int step,
                      float lr, float beta1, float beta2, float eps, float weight_decay,
-                     float grad_scale, void* w_bf16, void* stream);
+                     float grad_scale, void* w_bf16, const capdec_adam_panels* panels, void* stream);
 
 /* Greedy bookkeeping: ids[b] <- pad where done[b]; done[b] |= ids[b]==eos; out[b*L+t] = ids[b]. */
 int capdec_greedy_update(int64_t* ids, uint8_t* done, int64_t* out, int B, int L, int t,

@@ -33,16 +33,16 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "capdec.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "capdec.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(capdec_dropout), sizeof(capdec_gemm_desc), sizeof(capdec_attn_desc), sizeof(capdec_attn_bwd_desc),'
                    'offsetof(capdec_gemm_desc, kv_cache), offsetof(capdec_attn_desc, lse), offsetof(capdec_attn_bwd_desc, delta),'
-                   'sizeof(capdec_kpanels), sizeof(capdec_decode_desc), offsetof(capdec_decode_desc, head_w_panels));return 0;}\n')
+                   'sizeof(capdec_kpanels), sizeof(capdec_decode_desc), offsetof(capdec_decode_desc, head_w_panels), sizeof(capdec_adam_panels));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(_lib.Dropout), ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.AttnBwdDesc),
             _lib.GemmDesc.kv_cache.offset, _lib.AttnDesc.lse.offset, _lib.AttnBwdDesc.delta.offset,
-            ctypes.sizeof(_lib.KPanels), ctypes.sizeof(_lib.DecodeDesc), _lib.DecodeDesc.head_w_panels.offset]
+            ctypes.sizeof(_lib.KPanels), ctypes.sizeof(_lib.DecodeDesc), _lib.DecodeDesc.head_w_panels.offset, ctypes.sizeof(_lib.AdamPanels)]
     assert got == want
 
 

@@ -1018,6 +1018,21 @@ def test_elementwise_and_adam():
         opt.step()
     close(w, pw.data, 2e-6, "adam")
     assert torch.equal(wb, w.to(torch.bfloat16))
+    # the same update keeps the k-panel image of a matrix inside the buffer current: whole buffer, and slices that cut
+    # through the matrix (the data-parallel trainer updates bucket by bucket)
+    first, rows, K = 64, 37, 96
+    n2 = first + rows * K + 131
+    w2, g2 = rnd(n2, seed=70), rnd(n2, seed=71)
+    for cuts in ((0, n2), (0, 1000, 2048, n2)):
+        ww, m2, v2 = w2.clone(), torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
+        pan = torch.full(ops.kpanel_shape(rows + 2, K), 7.0, device=DEV, dtype=torch.bfloat16)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ops.adam_step(ww[lo:hi], g2[lo:hi], m2[lo:hi], v2[lo:hi], 1, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+                          panels=pan, panel_first=first - lo, panel_rows=rows)
+        mat = ww[first:first + rows * K].view(rows, K).to(torch.bfloat16)
+        assert torch.equal(pan[:, :rows], mat.view(rows, K // 32, 32).permute(1, 0, 2))
+        assert bool((pan[:, rows:] == 7.0).all())
+        assert not torch.equal(ww, w2)
     # greedy bookkeeping
     ids = torch.tensor([5, 7, 9], device=DEV)
     done = torch.tensor([0, 1, 0], dtype=torch.uint8, device=DEV)
