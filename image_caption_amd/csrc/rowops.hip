@@ -61,11 +61,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
                                                       float* xout, long x_row0, TOUT* y, float* mean, float* rstd) {
     const int lane = threadIdx.x & 63;
     const long nwaves = (long)gridDim.x * 4;
-    // a wave walks rows r, r + nwaves, ...: long-lived waves keep more bytes in flight than one wave per row
-    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += nwaves) {
-        float* xo = r < x_row0 ? nullptr : xout;          // the joined row itself is only kept from x_row0 on
-        f32x4 v[NV];
-        float sum = 0.f;
+    // a wave walks rows r, r + nwaves, ...: long-lived waves keep more bytes in flight than one wave per row, and the
+    // next row's loads are issued before the current row's two reductions, so a wave always has a row on its way
+    auto fetch = [&](long r, f32x4 (&v)[NV]) {
         long s = 0;
         const TIN* src = nullptr;
         if constexpr (CONCAT) {
@@ -81,38 +79,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* img, long img_bs
                 if constexpr (CONCAT) {
                     v[i] = load4_stream<TIN>(src + c);
                     if (pos) v[i] += *reinterpret_cast<const f32x4*>(pos + s * d + c);
-                    if (xo) *reinterpret_cast<f32x4*>(xo + r * d + c) = v[i];
                 } else {
                     v[i] = *reinterpret_cast<const f32x4*>(xin + r * d + c);
+                }
+            }
+        }
+    };
+    long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 v[NV], vn[NV];
+    if (r < M) fetch(r, v);
+    for (; r < M; r += nwaves) {
+        if (r + nwaves < M) fetch(r + nwaves, vn);
+        float* xo = r < x_row0 ? nullptr : xout;          // the joined row itself is only kept from x_row0 on
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
+                if constexpr (CONCAT) {
+                    if (xo) *reinterpret_cast<f32x4*>(xo + r * d + c) = v[i];
                 }
                 sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             }
         }
-        if (!y) continue;
-        const float mu = wave_sum(sum) / d;
-        float sq = 0.f;
+        if (y) {
+            const float mu = wave_sum(sum) / d;
+            float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane * 4 + i * 256;
-            if (c < d) {
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + i * 256;
+                if (c < d) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+                    for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+                }
+            }
+            const float rs = rsqrtf(wave_sum(sq) / d + eps);
+            if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + i * 256;
+                if (c < d) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
+                    store4<TOUT>(y + r * d + c, o);
+                }
             }
         }
-        const float rs = rsqrtf(wave_sum(sq) / d + eps);
-        if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane * 4 + i * 256;
-            if (c < d) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
-                store4<TOUT>(y + r * d + c, o);
-            }
-        }
+        for (int i = 0; i < NV; ++i) v[i] = vn[i];
     }
 }
 
