@@ -68,6 +68,8 @@ def parse():
                     help="data gradients of the vocabulary matrix, linear2 and out_proj on transposed weight copies (row-major second operand; A/B)")
     ap.add_argument("--no-head-k-panels", action="store_true",
                     help="the vocabulary product reads its operands row-major (A/B of the k-panel images)")
+    ap.add_argument("--no-dl-panels", action="store_true",
+                    help="the kept softmax numerators / d(logits) stay a row-major matrix (A/B of the column-panel image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
     ap.add_argument("--no-greedy", action="store_true")
@@ -309,6 +311,8 @@ def main():
             opts.wgrad_stream = False
         if args.no_head_k_panels:
             opts.head_k_panels = False
+        if args.no_dl_panels:
+            opts.dl_panels = False
         torch.manual_seed(42)                                           # config.py:27,41
         model = TransformerDecoder(768, 8, 6, 2048, 0.1, 50260, n_blocks=n_blocks, options=opts).to(dev)
         model.train()                                                   # decoder.py:144: dropout active

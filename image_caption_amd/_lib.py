@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_void_p), ("workspace_bytes", c_long),
         ("row_scale", c_void_p),
         ("kvec", c_void_p), ("kvec_out", c_void_p),
+        ("a_panel_rows", c_long),
     ]
 
 
@@ -109,7 +110,7 @@ class AdamPanels(C.Structure):
 
 
 class KPanels(C.Structure):
-    _fields_ = [("a", c_void_p), ("a_rows", c_long), ("b", c_void_p), ("b_rows", c_long)]
+    _fields_ = [("a", c_void_p), ("a_rows", c_long), ("b", c_void_p), ("b_rows", c_long), ("probs_rows", c_long)]
 
 
 # name -> (restype, argtypes); every symbol include/capdec.h declares
@@ -156,7 +157,7 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_long, c_void_p, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_ref_prepare": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int,
-                                                 c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_colsum_weighted": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,
                                      c_void_p, c_void_p, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),

@@ -83,7 +83,7 @@ extern "C" int capdec_decode_step(const capdec_decode_desc* p, void* stream) {
 
     // 1. score the newest row, pick the token, book-keep <eos>/<pad>
     CAPDEC_TRY(capdec_cast(p->x_last, CAPDEC_F32, s.hh, cdt, (long)B * d, stream));
-    const capdec_kpanels panels = {nullptr, 0, p->head_w_panels, p->head_w_panel_rows};
+    const capdec_kpanels panels = {nullptr, 0, p->head_w_panels, p->head_w_panel_rows, 0};
     CAPDEC_TRY(capdec_logits_argmax(s.hh, p->head_w, p->head_b, cdt, B, p->vocab, d, d, p->ld_head_w ? p->ld_head_w : d,
                                     p->ids, p->margin, p->head_w_panels ? &panels : nullptr, s.argmax_ws, s.argmax_ws_bytes, stream));
     CAPDEC_TRY(capdec_greedy_update(p->ids, p->done, p->out, B, p->max_len, p->t, p->eos_id, p->pad_id, stream));

@@ -1486,7 +1486,10 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         t_kvec_done = true;                                                                            \
     } while (0)
         if (g_dbg_a_panel && kern == KERN_QUAD) a.a_panel = g_dbg_a_panel;
-        CAPDEC_CHECK(!a.a_panel || kern == KERN_QUAD, "gemm: a column-panel image of A is read by the pipelined 256x256 kernel only");
+        if (a.a_panel) {      // only the pipelined 256x256 kernel reads such an image
+            CAPDEC_CHECK(EPI == EPI_STD && (a.K % DBK) == 0 && a.K >= DBK, "gemm: a column-panel image of A goes with plain products, K %% 32 == 0");
+            kern = KERN_QUAD;
+        }
         if (kern == KERN_TALLP) {
             if constexpr (EPI == EPI_STD) {
                 if (a.a_kmajor && a.b_kmajor) CAPDEC_PIPE_LAUNCH(true, true, EPI_STD, 4, big_tiles);
@@ -1703,8 +1706,12 @@ __global__ __launch_bounds__(256) void label_logit_kernel(const bf16_t* h, long 
 // Rows the finalize pass flagged (numerators against the label's logit out of the safe range: a label the model gives
 // a probability below e^-50) are redone here against their own maximum, one workgroup per row and plain dot products:
 // slow, and expected to run for no row at all.  Rewrites the row of numerators, its reference, lse and loss.
+// element (m, v) of the numerators: a matrix [M][ld], or (prows > 0) a column-panel image [ld / 32][prows][32]
+__device__ __forceinline__ long probs_index(long m, long v, long ld, long prows) {
+    return prows ? ((v >> 5) * prows + m) * 32 + (v & 31) : m * ld + v;
+}
 __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowflag, const bf16_t* h, long ldh, const bf16_t* W, long ldw,
-                                                            const float* bias, int d, int V, bf16_t* probs, long ld,
+                                                            const float* bias, int d, int V, bf16_t* probs, long ld, long prows,
                                                             float* rowref, float* lse, float* rowloss) {
     const long m = blockIdx.x;
     if (!rowflag[m]) return;
@@ -1732,7 +1739,7 @@ __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowfla
     for (int v = threadIdx.x; v < ld; v += 256) {
         const float e = v < V ? __expf(logit(v) - mx) : 0.f;
         sum += e;
-        probs[m * ld + v] = (bf16_t)e;
+        probs[probs_index(m, v, ld, prows)] = (bf16_t)e;
     }
     sum = wave_sum(sum);
     if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = sum;
@@ -1747,7 +1754,7 @@ __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowfla
 //   d(logits)[m, v] = g_m * e'[m, v],   e' = e except e'[m, label] = e[m, label] - exp(lse_m - ref_m).
 // One wave per row: patches the label's numerator, writes rowscale[m] = g_m and hs[m, :] = g_m * h[m, :] (the weight
 // gradient's second operand; the data gradient applies g_m to its rows instead).
-__global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, long ld, const bf16_t* h, long ldh, int d,
+__global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, long ld, long prows, const bf16_t* h, long ldh, int d,
                                                                   const int64_t* labels, int ce_B, int ce_L, long M,
                                                                   const float* lse, const float* rowref, float gscale,
                                                                   bf16_t* hs, long ldhs, float* rowscale, bf16_t* rowscale_lp) {
@@ -1767,7 +1774,7 @@ __global__ __launch_bounds__(256) void ce_ref_bwd_prepare_kernel(bf16_t* probs, 
         rowscale[m] = g;
         if (rowscale_lp) rowscale_lp[m] = (bf16_t)g;
         const long l = m / ce_B, b = m - l * ce_B;
-        bf16_t* pl = probs + m * ld + labels[b * ce_L + l];
+        bf16_t* pl = probs + probs_index(m, labels[b * ce_L + l], ld, prows);
         *pl = (bf16_t)((float)*pl - __expf(-e));
     }
 }
@@ -2018,6 +2025,7 @@ extern "C" int capdec_gemm_bias_act(const capdec_gemm_desc* d, void* stream) {
     const int rc = gemm_bias_act_impl(d, stream);
     if (rc || d->M == 0 || d->N == 0) { t_row_scaled = true; t_kvec_done = true; return rc; }
     hipStream_t st = (hipStream_t)stream;
+    CAPDEC_CHECK(!(d->kvec_out && !t_kvec_done && d->a_panel_rows), "gemm: kvec with a column-panel image of A needs a k range of at most 8192 per workgroup");
     if (d->kvec_out && !t_kvec_done) {     // the kernel that ran does not form the vector product: a pass over A, in up to 32
                                            // k chunks through the end of the workspace when there is one
         const long kv_bytes = 32L * d->M * 4;
@@ -2073,7 +2081,8 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             h1.M = (int)m0;
             h1.workspace = nullptr; h1.workspace_bytes = 0;
             t1.M = d->M - (int)m0;
-            t1.A = (const char*)d->A + (d->a_kmajor ? m0 : m0 * d->lda) * esz;
+            t1.A = (const char*)d->A + (d->a_panel_rows ? (d->a_kmajor ? (m0 >> 5) * d->a_panel_rows * 32 : m0 * 32)
+                                                        : (d->a_kmajor ? m0 : m0 * d->lda)) * esz;
             t1.C = (char*)d->C + m0 * d->ldc * osz;
             if (d->row_scale) t1.row_scale = d->row_scale + m0;
             if (d->kvec_out) t1.kvec_out = d->kvec_out + m0;
@@ -2103,6 +2112,12 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     a.kv_cache = d->kv_cache; a.kv_q = d->kv_q; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
     a.kv_smax = d->kv_smax; a.kv_s0 = d->kv_s0;
     a.kvec = (const bf16_t*)d->kvec; a.kvec_out = d->kvec_out; a.kvec_out_stride = 0;
+    if (d->a_panel_rows) {
+        CAPDEC_CHECK(d->in_dtype == CAPDEC_BF16 && (d->K % 32) == 0 && d->a_panel_rows >= (d->a_kmajor ? d->K : d->M) && !d->bias && d->col_scale_n == 0 &&
+                     d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual && !d->gate && !d->aux_out && !d->colsum && !d->kv_cache,
+                     "gemm: a column-panel image of A goes with plain bf16 products, K %% 32 == 0, a_panel_rows >= the stored matrix's rows");
+        a.a_panel = d->a_panel_rows;
+    }
     if (a.kv_cache) {
         CAPDEC_CHECK(a.kv_d > 0 && a.kv_B > 0 && a.kv_H > 0 && a.kv_hd > 0 && a.kv_H * a.kv_hd == a.kv_d && (a.kv_hd % 4) == 0,
                      "gemm: inconsistent kv scatter geometry");
@@ -2275,7 +2290,7 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
                                     void* probs, long ld_probs, const capdec_kpanels* panels,
                                     void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && labels && lse && loss_sum && correct, "logits_ce_fwd: null pointer");
-    CAPDEC_CHECK(panels_ok(panels, M, V), "logits_ce_fwd: k-panel images must be 16-byte aligned and hold at least M / V rows per panel");
+    CAPDEC_CHECK(panels_ok(panels, M, V) && (!panels || panels->probs_rows == 0), "logits_ce_fwd: k-panel images must be 16-byte aligned and hold at least M / V rows per panel (probs_rows: capdec_logits_ce_fwd_ref only)");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_fwd: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(!probs || (ld_probs >= V && (ld_probs % 8) == 0 && ld_probs <= (long)((V + BN - 1) / BN) * BN && aligned16(probs)),
                  "logits_ce_fwd: ld_probs (%ld) must be a multiple of 8 in [V, roundup128(V)] and probs 16-byte aligned", ld_probs);
@@ -2335,6 +2350,9 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
     ha.lda = ldh; ha.ldb = ldw; ha.ldc = ld_probs; ha.M = (int)M; ha.N = V; ha.K = d; ha.store_cols = (int)ld_probs;
     ha.part4 = ws.part4; ha.np = ws.np; ha.mode = 3; ha.rowref = rowref;
     set_panels(ha, panels);
+    const long prows = panels ? panels->probs_rows : 0;
+    CAPDEC_CHECK(prows == 0 || (prows >= M && (ld_probs % 32) == 0), "logits_ce_fwd_ref: a column-panel image of probs needs probs_rows >= M and ld_probs %% 32 == 0");
+    ha.c_panel_rows = prows;
     CAPDEC_CHECK(head_fwd_supported(ha), "logits_ce_fwd_ref: shape not supported (d %% 32 == 0, d >= 256, 16-byte aligned rows)");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(label_logit_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)h, ldh, (const bf16_t*)W, ldw, bias, d,
@@ -2345,7 +2363,7 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
                        ws.part4, (const float*)rowref, labels, B, L, M, ws.np,
                        lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, LabelDot{}, ws.rowflag);
     hipLaunchKernelGGL(ce_ref_fixup_kernel, dim3((unsigned)M), dim3(256), 0, st, (const int32_t*)ws.rowflag, (const bf16_t*)h, ldh,
-                       (const bf16_t*)W, ldw, bias, d, V, (bf16_t*)probs, ld_probs, rowref, lse, ws.rowloss);
+                       (const bf16_t*)W, ldw, bias, d, V, (bf16_t*)probs, ld_probs, prows, rowref, lse, ws.rowloss);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -2355,13 +2373,15 @@ extern "C" int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long
                                                 const void* h, long ldh, int d,
                                                 const int64_t* labels, int B, int L,
                                                 const float* lse, const float* rowref, float gscale,
-                                                void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16, void* stream) {
+                                                void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16,
+                                                long probs_panel_rows, void* stream) {
     CAPDEC_CHECK(probs && h && labels && lse && rowref && h_scaled && rowscale, "logits_ce_bwd_ref_prepare: null pointer");
     CAPDEC_CHECK(M == (long)B * L && M < (1L << 31), "logits_ce_bwd_ref_prepare: M (%ld) must equal B*L", M);
     CAPDEC_CHECK(ld_probs >= V && (d % 8) == 0 && (ldh % 8) == 0 && (ld_hs % 8) == 0 && ld_hs >= d && aligned16(h) && aligned16(h_scaled),
                  "logits_ce_bwd_ref_prepare: rows of h / h_scaled must be 16-byte aligned, d a multiple of 8");
     if (M == 0) return CAPDEC_OK;
-    hipLaunchKernelGGL(ce_ref_bwd_prepare_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)probs, ld_probs,
+    CAPDEC_CHECK(probs_panel_rows == 0 || (probs_panel_rows >= M && (ld_probs % 32) == 0), "logits_ce_bwd_ref_prepare: probs_panel_rows must be 0 or >= M, with ld_probs %% 32 == 0");
+    hipLaunchKernelGGL(ce_ref_bwd_prepare_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)probs, ld_probs, probs_panel_rows,
                        (const bf16_t*)h, ldh, d, labels, B, L, M, lse, rowref, gscale, (bf16_t*)h_scaled, ld_hs, rowscale, (bf16_t*)rowscale_bf16);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -2372,7 +2392,7 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
                                     int64_t* out_ids, float* margin, const capdec_kpanels* panels,
                                     void* workspace, long workspace_bytes, void* stream) {
     CAPDEC_CHECK(h && W && out_ids, "logits_argmax: null pointer");
-    CAPDEC_CHECK(panels_ok(panels, M, V), "logits_argmax: k-panel images must be 16-byte aligned and hold at least M / V rows per panel");
+    CAPDEC_CHECK(panels_ok(panels, M, V) && (!panels || panels->probs_rows == 0), "logits_argmax: k-panel images must be 16-byte aligned and hold at least M / V rows per panel (probs_rows: capdec_logits_ce_fwd_ref only)");
     CAPDEC_CHECK(M < (1L << 31), "logits_argmax: M too large");
     CeWs ws;
     if (!carve_ce_ws(workspace, workspace_bytes, M, V, ws)) {

@@ -248,7 +248,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
     const unsigned qbits = (unsigned)(3 - q) << 2;
     // numerators: after the swap a lane holds 8 consecutive columns starting at colq (+ 32 for the second pair of tiles)
     const int colq = (q & 1) ? 16 + 4 * (q - 1) : 4 * q;
-    const unsigned c_lane_off = (unsigned)(((long)r16 * p.ldc + colq) * 2);
+    // C as a matrix: row pitch ldc, a lane's second 8 columns 64 bytes on; as a column-panel image [ldc / 32][rows][32]: row
+    // pitch 32 elements, the second 8 columns one panel (rows x 64 bytes) on
+    const bool c_img = (MODE == 0 || MODE == 3) && p.c_panel_rows > 0;
+    const unsigned c_lane_off = (unsigned)(((long)r16 * (c_img ? 32 : p.ldc) + colq) * 2);
+    const unsigned c_pair_off = c_img ? (unsigned)(p.c_panel_rows * 64) : 64u;
     for (;;) {
         const int vnext = vb + gridDim.x;
         int mn, nn;
@@ -368,7 +372,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                 }
             }
             if constexpr (KEEP && MODE != 2) {
-                const __amdgpu_buffer_rsrc_t crs = rsrc_at((const char*)(p.C + (long)mb * p.ldc + nw), 0xFFFFFFF0L);
+                const __amdgpu_buffer_rsrc_t crs = rsrc_at((const char*)(c_img ? p.C + ((long)(nw >> 5) * p.c_panel_rows + mb) * 32
+                                                                                       : p.C + (long)mb * p.ldc + nw), 0xFFFFFFF0L);
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     // tiles 2jp and 2jp+1: this lane's 4 + 4 columns become 8 consecutive ones of one of them
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                     const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                     const bool ok = row_ok && colq + 32 * jp < p.store_cols - nw;
-                    const unsigned off = ok ? c_lane_off + 64u * jp : 0xFFFFFFFFu;
+                    const unsigned off = ok ? c_lane_off + c_pair_off * jp : 0xFFFFFFFFu;
                     // ordinary write-back stores: inside a training step (the caches full of other kernels' data) the
                     // streaming forms (nt, write-through) made the whole launch 5-10 % slower, though they win when
                     // the launch is repeated back to back
@@ -478,6 +483,8 @@ bool head_fwd_supported(const HeadFwdArgs& a) {
     if (a.mode == 1 && (!a.C || (a.col_scale_n % 64) != 0 || (a.N % 8) != 0 || a.store_cols != a.N)) return false;
     if (a.mode == 2 && (a.C || !a.Cf || !a.residual || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ldr % 4) != 0 || !aligned16(a.Cf) ||
                         !aligned16(a.residual) || 256L * a.ldc * 4 >= 0x7FFFFFFFL || 256L * a.ldr * 4 >= 0x7FFFFFFFL)) return false;
+    if (a.c_panel_rows && ((a.mode != 0 && a.mode != 3) || !a.C || a.c_panel_rows < a.M || (a.ldc % 32) != 0 || a.store_cols != a.ldc ||
+                           a.c_panel_rows * 64 >= 0x7FFFFFFFL)) return false;
     return a.K >= 8 * DBK && (a.K % DBK) == 0 && (a.lda % 8) == 0 && (a.ldb % 8) == 0 && aligned16(a.A) && aligned16(a.B) &&
            (!a.C || ((a.ldc % 8) == 0 && (a.store_cols % 8) == 0 && aligned16(a.C))) &&
            (long)a.np * a.M * 16 < 0xFFFFFFF0L && 256L * a.lda * 2 < 0x7FFFFFFFL && 256L * a.ldb * 2 < 0x7FFFFFFFL &&

@@ -63,6 +63,7 @@ class EngineOptions:
     composed_decode_step: bool = True             # greedy decoding: one capdec_decode_step call per token (False: a dozen calls)
     scored_rows_only: bool = True                 # last block: Q / MLP only for the rows the loss reads (exact)
     fold_norm1: bool = True                       # training without input gradient: block 0's norm1 affine is folded into in_proj
+    dl_panels: bool = True                        # the kept numerators / d(logits) are stored as a column-panel image [V/32][rows][32]
     head_k_panels: bool = True                    # the vocabulary product reads k-panel images ([d/32][rows][32]) of h and of the vocabulary
                                                   # matrix: whole 128-byte lines per load instead of half lines (bit-identical results)
     dropout_seed: int = 42
@@ -476,6 +477,14 @@ class DecoderEngine:
         dl = self.buf("ce_dl", (Mh, (slab + 127) // 128 * 128), cdt, dev) if want_grads else None
         by_row = from_probs and self.opt.ce_row_reference and cdt == torch.bfloat16 and d % 32 == 0 and d >= 256
         self.last_by_row = by_row
+        # d(logits) as a column-panel image [Vp/32][Mh][32] (same bytes, same buffer): the data gradient then reads its
+        # 32-deep steps as whole lines.  Only where both backward products run on the pipelined 256x256 kernel anyway and
+        # the bias gradient rides on the weight-gradient product (nothing else reads the numerators).
+        dl_img = (by_row and self.opt.dl_panels and self.opt.ce_bias_in_wgrad and not self.opt.dgrad_transposed_weights and
+                  2048 <= Mh <= 8192 and Mh % 256 == 0 and dl.shape[1] <= V + W.head_pad_rows)
+        self.last_dl_panels = dl_img
+        if dl_img:
+            dl = dl.view(dl.shape[1] // 32, Mh, 32)
         head_wt = head_wt_ready = None
         if by_row and self.opt.dgrad_transposed_weights:
             # W^T for the data gradient, made beside the forward product (the second stream is idle until the backward)
@@ -515,7 +524,7 @@ class DecoderEngine:
                 # the bias gradient is one more column of the weight-gradient product (numerators^T . rowscale): formed by that
                 # product's kernel on the way instead of by a pass over the numerators
                 with self._span("head_wgrad_slab"):
-                    ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws, kvec=rowscale_lp, kvec_out=gb)
+                    ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws, kvec=rowscale_lp, kvec_out=gb, a_panels=dl_img)
             else:
                 # on this stream: the products' workgroups take a CU's whole register file, so a pass running beside them
                 # only takes CUs away from them (on a second stream it cost the weight gradient twice its own duration)
@@ -525,9 +534,11 @@ class DecoderEngine:
                     ops.gemm(dl, hs, gW, M=V, N=d, K=Mh, a_kmajor=True, b_kmajor=True, workspace=hws)
             if on_grad_ready is not None:
                 on_grad_ready(HEAD_W, 0, V)
-            kk = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V
+            kk = dl.shape[0] * 32 if dl_img else (dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V)
             with self._span("head_dgrad_slab"):
-                if head_wt is not None:
+                if dl_img:
+                    ops.gemm(dl, W.head_w, dH, M=Mh, N=d, K=kk, b_kmajor=True, workspace=hws, row_scale=rowscale, a_panels=True)
+                elif head_wt is not None:
                     torch.cuda.current_stream().wait_event(head_wt_ready)
                     ops.gemm(dl, head_wt, dH, M=Mh, N=d, K=kk, workspace=hws, row_scale=rowscale)
                 else:

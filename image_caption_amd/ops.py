@@ -160,11 +160,16 @@ def _ld(t: torch.Tensor) -> int:
 
 def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
          act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
-         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None, kvec=None, kvec_out=None):
+         gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None, kvec=None, kvec_out=None,
+         a_panels=False):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
-    B is [N,K] (or [K,N] if b_kmajor)."""
+    B is [N,K] (or [K,N] if b_kmajor).  a_panels: A is the column-panel image [cols/32, R, 32] of that stored matrix
+    (M and K must then be given)."""
     require_cuda(A, B, Cout, bias, residual, gate, aux_out, colsum, kv_cache, row_scale, kvec, kvec_out)
     assert A.dtype == B.dtype
+    if a_panels:
+        assert A.dim() == 3 and A.shape[2] == 32 and A.is_contiguous() and M is not None and K is not None
+        assert A.shape[1] >= (K if a_kmajor else M) and A.shape[0] * 32 >= (M if a_kmajor else K)
     if M is None:
         M = A.shape[1] if a_kmajor else A.shape[0]
     if K is None:
@@ -174,7 +179,9 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
     d = GemmDesc()
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb, d.ldc = _ld(A), _ld(B), _ld(Cout)
+    d.lda, d.ldb, d.ldc = (32 if a_panels else _ld(A)), _ld(B), _ld(Cout)
+    if a_panels:
+        d.a_panel_rows = A.shape[1]
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
     d.in_dtype, d.out_dtype = dtype_code(A), dtype_code(Cout)
     d.bias = ptr(bias)
@@ -304,7 +311,7 @@ def _kpanels(h_panels, w_panels, M, V, d):
         assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape[0] == d // 32 and t.shape[1] >= n and t.shape[2] == 32)
     require_cuda(h_panels, w_panels)
     return _lib.KPanels(ptr(h_panels), h_panels.shape[1] if h_panels is not None else 0,
-                        ptr(w_panels), w_panels.shape[1] if w_panels is not None else 0)
+                        ptr(w_panels), w_panels.shape[1] if w_panels is not None else 0, 0)
 
 
 def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs=None, h_panels=None, w_panels=None):
@@ -321,6 +328,11 @@ def logits_ce_fwd(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, work
                                            ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd")
 
 
+def probs_panel_shape(M: int, V: int):
+    """Shape of the column-panel image of the numerators / d(logits) [M, roundup128(V)]: [Vp / 32, M, 32]."""
+    return ((V + 127) // 128 * 4, M, 32)
+
+
 def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, workspace, probs, rowref, h_panels=None, w_panels=None):
     """logits_ce_fwd with the numerators kept against one reference per row (rowref [M] f32, written here): probs [M, ld] bf16
     = exp(z - rowref).  The backward starts from logits_ce_bwd_ref_prepare."""
@@ -328,12 +340,27 @@ def logits_ce_fwd_ref(h, W, bias, labels, B, L, lse, argmax, loss_sum, correct, 
     M, d = h.shape
     V = W.shape[0]
     assert labels.dtype == torch.int64 and labels.is_contiguous()
-    assert probs.dtype == h.dtype == torch.bfloat16 and probs.shape[0] == M
+    assert probs.dtype == h.dtype == torch.bfloat16
     assert rowref.dtype == torch.float32 and rowref.numel() == M and rowref.is_contiguous()
+    kp = _kpanels(h_panels, w_panels, M, V, d)
+    ld_probs, prows = _probs_layout(probs, M)
+    if prows:
+        kp = kp if kp is not None else _lib.KPanels(None, 0, None, 0, 0)
+        kp.probs_rows = prows
     check(_lib.load().capdec_logits_ce_fwd_ref(ptr(h), ptr(W), ptr(bias), dtype_code(h), M, V, d, _ld(h), _ld(W), ptr(labels), B, L,
                                                ptr(lse), ptr(argmax), ptr(loss_sum), ptr(correct),
-                                               ptr(probs), _ld(probs), ptr(rowref), _kpanels(h_panels, w_panels, M, V, d), ptr(workspace),
+                                               ptr(probs), ld_probs, ptr(rowref), kp, ptr(workspace),
                                                workspace.numel() * workspace.element_size(), _st()), "capdec_logits_ce_fwd_ref")
+
+
+def _probs_layout(probs, M):
+    """(leading dimension, rows per panel) of a numerator buffer: a matrix [M, ld] (rows per panel 0) or its column-panel
+    image [ld / 32, R >= M, 32] (probs_panel_shape)."""
+    if probs.dim() == 3:
+        assert probs.is_contiguous() and probs.shape[2] == 32 and probs.shape[1] >= M
+        return probs.shape[0] * 32, probs.shape[1]
+    assert probs.shape[0] == M
+    return _ld(probs), 0
 
 
 def logits_ce_bwd_ref_prepare(probs, V, h, labels, B, L, lse, rowref, gscale, h_scaled, rowscale, rowscale_bf16=None):
@@ -342,10 +369,12 @@ def logits_ce_bwd_ref_prepare(probs, V, h, labels, B, L, lse, rowref, gscale, h_
     require_cuda(probs, h, labels, lse, rowref, h_scaled, rowscale, rowscale_bf16)
     assert rowscale_bf16 is None or (rowscale_bf16.dtype == torch.bfloat16 and rowscale_bf16.numel() == h.shape[0])
     M, d = h.shape
-    assert probs.shape[0] == M and h_scaled.shape == (M, d) and h_scaled.dtype == h.dtype == torch.bfloat16
+    assert h_scaled.shape == (M, d) and h_scaled.dtype == h.dtype == torch.bfloat16
     assert rowscale.dtype == torch.float32 and rowscale.numel() == M
-    check(_lib.load().capdec_logits_ce_bwd_ref_prepare(ptr(probs), _ld(probs), M, V, ptr(h), _ld(h), d, ptr(labels), B, L,
-                                                       ptr(lse), ptr(rowref), gscale, ptr(h_scaled), _ld(h_scaled), ptr(rowscale), ptr(rowscale_bf16), _st()),
+    ld_probs, prows = _probs_layout(probs, M)
+    check(_lib.load().capdec_logits_ce_bwd_ref_prepare(ptr(probs), ld_probs, M, V, ptr(h), _ld(h), d, ptr(labels), B, L,
+                                                       ptr(lse), ptr(rowref), gscale, ptr(h_scaled), _ld(h_scaled), ptr(rowscale), ptr(rowscale_bf16),
+                                                       prows, _st()),
           "capdec_logits_ce_bwd_ref_prepare")
 
 

@@ -170,6 +170,11 @@ typedef struct {
      * (the bias gradient of a Linear next to its weight gradient: with ones, the column sums of the reduction-major
      * operand).  With a workspace, 32*M*4 bytes at its end are used for this. */
     const void* kvec; float* kvec_out;
+    /* 0: A is the matrix lda describes.  R > 0 (plain bf16 products, K % 32 == 0): A's stored matrix X -- [M][K], or [K][M]
+     * when a_kmajor -- lies as a column-panel image [cols / 32][R][32] (R >= its row count; element (r, c) at
+     * ((c / 32) * R + r) * 32 + c % 32; lda unused): what capdec_logits_ce_fwd_ref writes with capdec_kpanels.probs_rows.
+     * A row-major A read in 32-deep steps then comes in whole 128-byte lines. */
+    long a_panel_rows;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);
@@ -247,6 +252,10 @@ long capdec_logits_ce_workspace(long M, int V);
 typedef struct {
     const void* a; long a_rows;
     const void* b; long b_rows;
+    long probs_rows;   /* capdec_logits_ce_fwd_ref only, 0 elsewhere.  0: probs is the matrix [M, ld_probs]; R >= M: probs is written
+                        * as a column-panel image [ld_probs / 32][R][32] (ld_probs % 32 == 0): element (m, v) at
+                        * ((v / 32) * R + m) * 32 + v % 32.  The data gradient then reads its 32-deep steps of d(logits) as whole
+                        * lines too (capdec_gemm_desc.a_panel_rows); capdec_logits_ce_bwd_ref_prepare takes the same R. */
 } capdec_kpanels;
 /* panels[k / 32][r][k % 32] = bf16(src[r, k]) for r < rows, k < K (K % 32 == 0; src f32 or bf16 [rows, ld_src], rows
  * 16-byte aligned; panels 16-byte aligned, panel_rows >= rows rows per panel -- rows rows..panel_rows-1 are not written).
@@ -309,7 +318,8 @@ int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
                                      const void* h, long ldh, int d,
                                      const int64_t* labels, int B, int L,
                                      const float* lse, const float* rowref, float gscale,
-                                     void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16, void* stream);
+                                     void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16,
+                                     long probs_panel_rows, void* stream);
 /* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
  * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
 int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,

@@ -311,6 +311,64 @@ def test_logits_ce_forward_from_k_panels(gemm_mode, mode, B_, L, V, d, extra):
                                    y.view(torch.int16) if y.dtype == torch.bfloat16 else torch.nan_to_num(y))
 
 
+@pytest.mark.parametrize("B_,L,V,d,extra,hot_rows", [
+    (8, 32, 2000, 256, 0, 0),          # one M-tile, ragged vocabulary
+    (37, 32, 1111, 288, 3, 0),         # 1184 rows: ragged last M-tile, rows to spare per panel
+    (64, 32, 50260, 768, 0, 0),        # the benchmark's vocabulary: tail split of the weight gradient, split-K data gradient
+    (16, 32, 5000, 256, 0, 5),         # rows redone against their maximum write into the image too
+])
+def test_numerators_as_column_panel_image(B_, L, V, d, extra, hot_rows):
+    """capdec_logits_ce_fwd_ref writing the numerators as a column-panel image [Vp/32][R][32], the patch of
+    capdec_logits_ce_bwd_ref_prepare in that layout, and both backward products reading the image (A row-major for the data
+    gradient, reduction-major for the weight gradient with the bias column) -- against the same calls on the matrix."""
+    M = B_ * L
+    if M % 32:
+        pytest.skip("the weight gradient reads the image along its rows: whole 32-row steps only")
+    h = rnd(M, d, dtype=torch.bfloat16, seed=371)
+    if hot_rows:
+        h[:hot_rows] *= 40.0
+    w = rnd(V, d, dtype=torch.bfloat16, scale=2.0 / math.sqrt(d), seed=372)
+    b = rnd(V, seed=373)
+    labels = torch.randint(0, V, (B_, L), generator=torch.Generator().manual_seed(374)).to(DEV)
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    Vp = (V + 127) // 128 * 128
+    R = M + extra
+    outs = []
+    for img in (False, True):
+        lse, amax = torch.full((M,), float("nan"), device=DEV), torch.full((M,), -1, dtype=torch.int32, device=DEV)
+        ls, cr = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+        dl = torch.full((Vp // 32, R, 32) if img else (M, Vp), float("nan"), device=DEV, dtype=torch.bfloat16)
+        rowref = torch.full((M,), float("nan"), device=DEV)
+        ops.logits_ce_fwd_ref(h, w, b, labels, B_, L, lse, amax, ls, cr, ws, dl, rowref)
+        as_matrix = (lambda t: t[:, :M].permute(1, 0, 2).reshape(M, Vp)) if img else (lambda t: t)
+        num = as_matrix(dl).clone()
+        hs = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+        rowscale = torch.full((M,), float("nan"), device=DEV)
+        rowscale_lp = torch.full((M,), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B_, L, lse, rowref, 1.0 / M, hs, rowscale, rowscale_lp)
+        patched = as_matrix(dl).clone()
+        if img and extra:
+            assert bool(torch.isnan(dl[:, M:].float()).all())                     # the spare rows of every panel are untouched
+        hws = torch.empty(8 * M * d * 4, dtype=torch.uint8, device=DEV)
+        gW, gb = torch.full((V, d), float("nan"), device=DEV), torch.full((V,), float("nan"), device=DEV)
+        dH = torch.full((M, d), float("nan"), device=DEV)
+        wpad = torch.zeros(Vp, d, device=DEV, dtype=torch.bfloat16)
+        wpad[:V] = w
+        ops.gemm(dl, hs, gW, M=V, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=hws, kvec=rowscale_lp, kvec_out=gb, a_panels=img)
+        if img:
+            ops.gemm(dl, wpad, dH, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws, row_scale=rowscale, a_panels=True)
+        else:
+            ops.gemm(dl, wpad, dH, M=M, N=d, K=Vp, b_kmajor=True, workspace=hws, row_scale=rowscale)
+        outs.append((lse, amax, ls, cr, rowref, num, patched, hs, rowscale, gW, gb, dH))
+    a, c = outs
+    for i in range(9):
+        assert torch.equal(a[i].view(torch.int16) if a[i].dtype == torch.bfloat16 else a[i], c[i].view(torch.int16) if c[i].dtype == torch.bfloat16 else c[i]), i
+    assert not bool(torch.isnan(a[5].float()).any())
+    close(c[9], a[9], 1e-3, "weight gradient from the image")
+    close(c[10], a[10], 1e-3, "bias column from the image")
+    close(c[11], a[11], 1e-3, "data gradient from the image")
+
+
 @pytest.mark.parametrize("mode", [8, 9])
 @pytest.mark.parametrize("B_,L,V,d,with_bias,hot_rows", [
     (5, 8, 1111, 256, True, 0),
