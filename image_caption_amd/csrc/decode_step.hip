@@ -10,6 +10,7 @@ inline long up(long n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct StepBuffers {
     void *hh, *hs, *qs, *os, *h2s, *a1s;      // compute dtype
+    void* hhp;                                // k-panel image of hh (bf16)
     float *xs, *xm, *xo[2];                   // f32 residual stream of the appended row
     void* argmax_ws;
     long argmax_ws_bytes;
@@ -33,6 +34,7 @@ StepBuffers carve(char* base, int B, int d, int ff, int V, int dtype) {
     s.xo[1] = (float*)take((long)B * d * 4);
     s.argmax_ws_bytes = capdec_logits_ce_workspace(B, V);
     s.argmax_ws = take(s.argmax_ws_bytes);
+    s.hhp = take((long)B * d * e);
     s.total = off;
     return s;
 }
@@ -82,8 +84,11 @@ extern "C" int capdec_decode_step(const capdec_decode_desc* p, void* stream) {
     const int cdt = p->dtype;
 
     // 1. score the newest row, pick the token, book-keep <eos>/<pad>
-    CAPDEC_TRY(capdec_cast(p->x_last, CAPDEC_F32, s.hh, cdt, (long)B * d, stream));
-    const capdec_kpanels panels = {nullptr, 0, p->head_w_panels, p->head_w_panel_rows, 0};
+    // with the vocabulary matrix's image given, the newest rows are cast and laid out as an image in one pass
+    const bool h_img = p->head_w_panels && cdt == CAPDEC_BF16 && (d % 32) == 0;
+    if (h_img) CAPDEC_TRY(capdec_pack_kpanels(p->x_last, CAPDEC_F32, B, d, d, s.hhp, B, s.hh, d, stream));
+    else CAPDEC_TRY(capdec_cast(p->x_last, CAPDEC_F32, s.hh, cdt, (long)B * d, stream));
+    const capdec_kpanels panels = {h_img ? s.hhp : nullptr, h_img ? (long)B : 0L, p->head_w_panels, p->head_w_panel_rows, 0};
     CAPDEC_TRY(capdec_logits_argmax(s.hh, p->head_w, p->head_b, cdt, B, p->vocab, d, d, p->ld_head_w ? p->ld_head_w : d,
                                     p->ids, p->margin, p->head_w_panels ? &panels : nullptr, s.argmax_ws, s.argmax_ws_bytes, stream));
     CAPDEC_TRY(capdec_greedy_update(p->ids, p->done, p->out, B, p->max_len, p->t, p->eos_id, p->pad_id, stream));

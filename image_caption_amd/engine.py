@@ -930,9 +930,13 @@ class DecoderEngine:
         a1s = self.buf("gen_a1s", (B, ff), cdt, dev)
         xo = [self.buf(f"gen_xo{j}", (B, d), torch.float32, dev) for j in range(2)]
         for t in range(max_len):
-            ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
+            hp = None
+            if w_panels is not None:
+                hp = ops.pack_kpanels(x_last, self.buf("gen_hh_panels", ops.kpanel_shape(B, d), cdt, dev), rowmajor=hh)
+            else:
+                ops.cast(x_last, hh) if cdt != torch.float32 else hh.copy_(x_last)
             with self._span("logits_argmax"):
-                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg if return_margins else None, ws, w_panels=w_panels)
+                ops.logits_argmax(hh, W.head_w, W.head_b, ids, mg if return_margins else None, ws, h_panels=hp, w_panels=w_panels)
             if return_margins:
                 margins[:, t].copy_(mg)
             ops.greedy_update(ids, done, out, t, eos_id, pad_id)

@@ -855,7 +855,7 @@ def test_attention_fwd_bwd(dtype, tol, B, H, S, hd, mode, prefix, p):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
-@pytest.mark.parametrize("S,hd,nq", [(50, 32, 9), (150, 96, 100), (300, 96, 70)])      # the last two: the whole-sequence kernels
+@pytest.mark.parametrize("S,hd,nq", [(50, 32, 9), (229, 96, 32), (130, 64, 20), (150, 96, 100), (300, 96, 70)])      # <= 32 queries: V staged in 64-key blocks; the last two: the whole-sequence kernels
 def test_attention_query_range(dtype, tol, S, hd, nq):
     # only the last nq queries are computed (scored rows of the last block)
     B, H = 2, 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention forward / backward timings at the two training shapes: scored rows of the one-block model
-(S = 229, last 33 queries) and all rows of the stacked model (S = 290).  Usage (GPU box): python tools/attn_bench.py"""
+(S = 229, last 32 queries) and all rows of the stacked model (S = 290).  Usage (GPU box): python tools/attn_bench.py"""
 import os
 import sys
 
@@ -29,7 +29,7 @@ def main():
     B, H, hd = 256, 8, 96
     d = H * hd
     g = torch.Generator(device=DEV).manual_seed(0)
-    for name, S, q_start, mode, prefix in (("one block, 33 scored queries, S=229", 229, 196, _lib.MASK_REFERENCE, 0),
+    for name, S, q_start, mode, prefix in (("one block, 32 scored queries, S=229", 229, 197, _lib.MASK_REFERENCE, 0),
                                             ("stacked, all 290 queries, prefix-causal", 290, 0, _lib.MASK_PREFIX_CAUSAL, 258)):
         nq = S - q_start
         qkv = (torch.randn(S * B, 3 * d, device=DEV, generator=g) * 0.5).to(BF)
