@@ -187,6 +187,11 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* lds, int rA, int rB, int
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
+// one LDS-DMA instruction: lane l's 16 bytes at base + off land at dst + 16 l (dst wave-uniform); bytes from `rem` on read as zero
+__device__ __forceinline__ void lds_dma_16(const bf16_t* base, long rem, unsigned off, char* dst) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rem > 0 ? (int)rem : 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst), 16, off, 0, 0, 0);
+}
 __device__ __forceinline__ bf16x8 zero_frag() {
     bf16x8 r;
 #pragma unroll
@@ -291,10 +296,15 @@ __device__ __forceinline__ int xcd_logical(int bid, int n) {
     return (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + (bid >> 3);
 }
 
-template <int HD, bool SEQ>
-__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(AttnArgs p) {
+// BLK = 1 or 2 (waves per workgroup; at most 32 queries, SEQ = false): V is not staged whole but in 64-key blocks, double
+// buffered by LDS-DMA: the next block is on its way while the current one is multiplied.  27 KB of LDS instead of 53
+// (S = 229): six workgroups per CU instead of three, each with a K and a V block in flight -- the kernel is bound by
+// the bytes it keeps in flight, not by its arithmetic.
+template <int HD, bool SEQ, int BLK = 0>
+__global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : 3) void attn_fwd_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
+    static_assert(!(SEQ && BLK), "block staging belongs to the slab form");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
     const int nthreads = blockDim.x;
@@ -314,13 +324,38 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(At
     const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
     bf16x8 kf[4][G::KS];
     if constexpr (!SEQ) frags_from_global<HD>(kbase, p.k_ss, 0, p.S, lane, kf);       // first key block, in flight during the staging of V
+    const bf16_t* vbase = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs;
+    // BLK: a 64-key block of V goes global -> LDS by LDS-DMA (no staging registers): 1-KiB pieces, lane l's 16 bytes land at
+    // piece base + 16 l, so a lane fetches the chunk that belongs at that position of the padded [64][ROWB] image (the
+    // pad chunk of a row fetches nothing); wave w issues pieces w, w + BLK, ...
+    constexpr int VPIECES = 64 * G::ROWB / 1024, VPW = BLK ? (VPIECES + BLK - 1) / BLK : 1;
+    static_assert(!BLK || (64 * G::ROWB) % 1024 == 0, "a V block is whole 1-KiB pieces");
+    unsigned voff[VPW];
+    if constexpr (BLK != 0) {
+#pragma unroll
+        for (int u = 0; u < VPW; ++u) {
+            const int pos = ((wave + u * BLK) * 64 + lane), row = pos / (G::CPR + 1), ch = pos - row * (G::CPR + 1);
+            voff[u] = ch < G::CPR ? (unsigned)(((long)row * p.v_ss + ch * 8) * 2) : 0xFFFFFFFFu;
+        }
+    }
+    auto dma_vblock = [&](int kb, char* buf) {
+        // rows from S on lie past the descriptor's range and arrive as zeros
+        const long rem = ((long)(p.S - kb - 1) * p.v_ss + HD) * 2;
+#pragma unroll
+        for (int u = 0; u < VPW; ++u) {
+            const int piece = wave + u * BLK;
+            if (piece < VPIECES) lds_dma_16(vbase + (long)kb * p.v_ss, rem, voff[u], buf + piece * 1024);
+        }
+    };
     if constexpr (SEQ) {
         __syncthreads();                                              // every wave is done with the previous head's images
-        pre.store(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
+        pre.store(Vl, vbase, p.v_ss, Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
+    } else if constexpr (BLK != 0) {
+        dma_vblock(0, Vl);
     } else {
-        rows_to_lds<HD>(Vl, (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs, p.v_ss, 0, p.S, SP, tid, nthreads);
+        rows_to_lds<HD>(Vl, vbase, p.v_ss, 0, p.S, SP, tid, nthreads);
     }
-    __syncthreads();
+    if constexpr (BLK == 0) __syncthreads();
     bool fetched = !SEQ || bh + (int)gridDim.x >= nheads;            // the next head's operands are on their way (or there is none)
     const int qend = min(p.q_start + p.nq, p.S);
     const int qstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);         // SEQ: the wave's next query tile
@@ -351,6 +386,14 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(At
             for (int ks = 0; ks < G::KS; ++ks) kf[t][ks] = frag_rows<HD>(Kl, t * 16, ks * 32, lane);
     }
     for (int kb = 0; kb < SP; kb += 64) {
+        const char* Vb = BLK ? Vl + ((kb >> 6) & 1) * 64 * G::ROWB : Vl + kb * G::ROWB;
+        if constexpr (BLK != 0) {
+            // this block's V (and K fragments) have landed; after the barrier every wave's pieces have, and every wave is done
+            // with the other buffer, which the next block's pieces may now overwrite
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kb + 64 < SP) dma_vblock(kb + 64, Vl + (((kb >> 6) + 1) & 1) * 64 * G::ROWB);
+        }
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -437,7 +480,7 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_fwd_mfma(At
 #pragma unroll
                 for (int dt = 0; dt < G::DT; ++dt)
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        frag_cols<HD>(Vl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
+                        frag_cols<HD>(Vb, (2 * st) * 16, (2 * st + 1) * 16, dt * 16, lane), pf[st], oacc[dt], 0, 0, 0);
         }
     }
     const float l = quad_sum<SEQ>(l_run);
@@ -987,6 +1030,10 @@ void set_lds(K kernel, int bytes) {
 }  // namespace
 
 // ==================================================================== C ABI
+namespace { int g_attn_blocks = 1; }
+// diagnostic hook (not part of the declared ABI): 0 = forwards of at most 32 queries stage V whole, as longer ranges do
+extern "C" void capdecdbg_attn_block_staging(int on) { g_attn_blocks = on; }
+
 extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
     AttnArgs a;
     int rc = fill_args(d, a);
@@ -1008,7 +1055,14 @@ extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
         } else {
             const int nwaves = a.nq >= 64 ? 4 : (a.nq + 15) / 16;        // a wave per 16 queries, at most 4 per workgroup
             dim3 grid(a.B * a.H, (a.nq + 16 * nwaves - 1) / (16 * nwaves)), block(64 * nwaves);
-            HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, false>, lds); hipLaunchKernelGGL((attn_fwd_mfma<HD, false>), grid, block, lds, st, a));
+            const int lds_blk = 2 * 64 * (a.hd * 2 + 16);                 // two 64-key blocks of V
+            if (nwaves == 1 && g_attn_blocks) {
+                HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, false, 1>, lds_blk); hipLaunchKernelGGL((attn_fwd_mfma<HD, false, 1>), grid, block, lds_blk, st, a));
+            } else if (nwaves == 2 && g_attn_blocks) {
+                HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, false, 2>, lds_blk); hipLaunchKernelGGL((attn_fwd_mfma<HD, false, 2>), grid, block, lds_blk, st, a));
+            } else {
+                HD_DISPATCH(a.hd, set_lds(attn_fwd_mfma<HD, false>, lds); hipLaunchKernelGGL((attn_fwd_mfma<HD, false>), grid, block, lds, st, a));
+            }
         }
     } else {
         const int lds = (a.hd + a.S) * 4;

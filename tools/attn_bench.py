@@ -26,6 +26,7 @@ def timeit(fn, reps=20):
 
 
 def main():
+    lib = _lib.load()
     B, H, hd = 256, 8, 96
     d = H * hd
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -41,6 +42,11 @@ def main():
             drop = ops.dropout_keys(1, 2, 3, p)
             kw = dict(q_start=q_start, nq=nq, mask_mode=mode, prefix_len=prefix, drop=drop)
             tf = timeit(lambda: ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, **kw))
+            if nq <= 32 and hasattr(lib, "capdecdbg_attn_block_staging"):
+                lib.capdecdbg_attn_block_staging(0)
+                tfb = timeit(lambda: ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, **kw))
+                lib.capdecdbg_attn_block_staging(1)
+                print(f"   forward with V staged whole instead of in 64-key blocks: {tfb:7.1f} us")
             tb = timeit(lambda: ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, **kw))
             fl = 4.0 * B * H * nq * S * hd
             kvb = 2.0 * B * S * d * 2
