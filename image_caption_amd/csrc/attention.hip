@@ -506,10 +506,14 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : 3) vo
 
 // ================================================================== backward: dQ (query-major)
 // SEQ as in the forward: one workgroup of 8 waves per (sequence, head), K and V both in LDS.
-template <int HD, bool SEQ>
-__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma(AttnArgs p) {
+// BLK = 1 or 2 (waves per workgroup; at most 32 queries, SEQ = false): K staged in 64-key blocks by LDS-DMA, double
+// buffered, as V is in the forward.  The next block is requested after the current block's last LDS read (the compiler
+// drains outstanding LDS-DMA before any LDS read it cannot tell apart from the DMA's target).
+template <int HD, bool SEQ, int BLK = 0>
+__global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK ? 2 : 3)) void attn_bwd_dq_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
+    static_assert(!(SEQ && BLK), "block staging belongs to the slab form");
     const int bh = xcd_logical(blockIdx.x, gridDim.x), b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int SP = (p.S + 63) & ~63;
@@ -519,9 +523,28 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma
     const bf16_t* vbase = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs;
     bf16x8 vf[4][G::KS];
     if constexpr (!SEQ) frags_from_global<HD>(vbase, p.v_ss, 0, p.S, lane, vf);       // V is only a row-major operand here: no LDS copy
-    if constexpr (SEQ) rows_to_lds2<HD, 8>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, Vl, vbase, p.v_ss, 0, p.S, SP, tid, nthreads);
-    else rows_to_lds<HD>(Kl, (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs, p.k_ss, 0, p.S, SP, tid, nthreads);
-    __syncthreads();
+    const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
+    constexpr int KPIECES = 64 * G::ROWB / 1024, KPW = BLK ? (KPIECES + BLK - 1) / BLK : 1;
+    unsigned koff[KPW];
+    if constexpr (BLK != 0) {
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            const int pos = ((wave + u * BLK) * 64 + lane), row = pos / (G::CPR + 1), ch = pos - row * (G::CPR + 1);
+            koff[u] = ch < G::CPR ? (unsigned)(((long)row * p.k_ss + ch * 8) * 2) : 0xFFFFFFFFu;
+        }
+    }
+    auto dma_kblock = [&](int kb, char* buf) {
+        const long rem = ((long)(p.S - kb - 1) * p.k_ss + HD) * 2;      // rows from S on arrive as zeros
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            const int piece = wave + u * BLK;
+            if (piece < KPIECES) lds_dma_16(kbase + (long)kb * p.k_ss, rem, koff[u], buf + piece * 1024);
+        }
+    };
+    if constexpr (SEQ) rows_to_lds2<HD, 8>(Kl, kbase, p.k_ss, Vl, vbase, p.v_ss, 0, p.S, SP, tid, nthreads);
+    else if constexpr (BLK != 0) dma_kblock(0, Kl);
+    else rows_to_lds<HD>(Kl, kbase, p.k_ss, 0, p.S, SP, tid, nthreads);
+    if constexpr (BLK == 0) __syncthreads();
     const int qend = min(p.q_start + p.nq, p.S);
     const int qstep = SEQ ? 16 * (nthreads >> 6) : (1 << 30);
     for (int qw = p.q_start + (SEQ ? 0 : blockIdx.y * (nthreads >> 2)) + wave * 16; qw < qend; qw += qstep) {
@@ -564,6 +587,11 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma
     };
     if constexpr (SEQ) read_rows(0, 0);
     for (int kb = 0; kb < SP; kb += 64) {
+        const char* Kb = BLK ? Kl + ((kb >> 6) & 1) * 64 * G::ROWB : Kl + kb * G::ROWB;
+        if constexpr (BLK != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's K pieces (and V fragments) have landed
+            __syncthreads();                                          // ... every wave's, and every wave is done with the other buffer
+        }
         u32x4 dsu[2];
         bf16x8 kcf[SEQ ? 2 : 1][SEQ ? G::DT : 1];
 #pragma unroll
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[t & 1][ks], qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[t & 1][ks], dof[ks], dp, 0, 0, 0);
                 } else {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kl, kb + t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kb, t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
                 }
             }
@@ -616,8 +644,11 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 1 : 3) void attn_bwd_dq_mfma
             for (int dt = 0; dt < G::DT; ++dt) {
                 if constexpr (SEQ) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf[st][dt], dsf[st], acc[dt], 0, 0, 0);
                 else acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        frag_cols<HD>(Kl, kb + (2 * st) * 16, kb + (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
+                        frag_cols<HD>(Kb, (2 * st) * 16, (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
             }
+        if constexpr (BLK != 0) {
+            if (kb + 64 < SP) dma_kblock(kb + 64, Kl + (((kb >> 6) + 1) & 1) * 64 * G::ROWB);
+        }
     }
     if (qok) {
         bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
@@ -1135,7 +1166,14 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
         } else if (a.nq > 0) {
             const int nwaves = pl.nwaves_q;
             dim3 gq(a.B * a.H, pl.nyq), bq(64 * nwaves);
-            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false>, lds_q); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false>), gq, bq, lds_q, st, a));
+            const int lds_blk = 2 * 64 * (a.hd * 2 + 16);                 // two 64-key blocks of K
+            if (nwaves == 1 && g_attn_blocks) {
+                HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false, 1>, lds_blk); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false, 1>), gq, bq, lds_blk, st, a));
+            } else if (nwaves == 2 && g_attn_blocks) {
+                HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false, 2>, lds_blk); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false, 2>), gq, bq, lds_blk, st, a));
+            } else {
+                HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, false>, lds_q); hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, false>), gq, bq, lds_q, st, a));
+            }
         }
         if (pl.seq_kv) {
             // many queries staged per workgroup: stage them once per (sequence, head) and walk every key tile

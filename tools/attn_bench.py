@@ -45,8 +45,9 @@ def main():
             if nq <= 32 and hasattr(lib, "capdecdbg_attn_block_staging"):
                 lib.capdecdbg_attn_block_staging(0)
                 tfb = timeit(lambda: ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, **kw))
+                tbb = timeit(lambda: ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, **kw))
                 lib.capdecdbg_attn_block_staging(1)
-                print(f"   forward with V staged whole instead of in 64-key blocks: {tfb:7.1f} us")
+                print(f"   with the LDS-resident operand staged whole instead of in 64-key blocks: fwd {tfb:7.1f} us, bwd {tbb:7.1f} us")
             tb = timeit(lambda: ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, **kw))
             fl = 4.0 * B * H * nq * S * hd
             kvb = 2.0 * B * S * d * 2
