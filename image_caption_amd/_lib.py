@@ -195,6 +195,10 @@ def load():
     got = lib.capdec_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"libcapdec ABI {got} != binding ABI {ABI_VERSION}: rebuild the library")
+    if os.environ.get("CAPDEC_HEAD_FWD_STORE_NT") and hasattr(lib, "capdecdbg_head_fwd_store_nt"):      # diagnostic
+        lib.capdecdbg_head_fwd_store_nt.argtypes = [c_int]
+        lib.capdecdbg_head_fwd_store_nt.restype = None
+        lib.capdecdbg_head_fwd_store_nt(int(os.environ["CAPDEC_HEAD_FWD_STORE_NT"]))
     geo = os.environ.get("CAPDEC_HEAD_FWD_GEOMETRY")      # diagnostic: tile geometry of the persistent logits+CE forward (0 / 1)
     if geo is not None and hasattr(lib, "capdecdbg_head_fwd_geometry"):
         lib.capdecdbg_head_fwd_geometry.argtypes = [c_int]

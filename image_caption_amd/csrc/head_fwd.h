@@ -30,6 +30,7 @@ struct HeadFwdArgs {
     // bytes one LDS-DMA instruction fetches are 1 KiB of consecutive bytes -- whole 128-byte lines instead of half lines
     const bf16_t* Ap; long a_rows;       // rows per panel of A's image (>= M)
     const bf16_t* Bp; long b_rows;       // rows per panel of B's image (>= N)
+    int store_nt;                        // modes 0 / 3: numerator stores non-temporal (set by head_fwd_launch)
     long c_panel_rows;                   // modes 0 / 3: > 0: C is written as a column-panel image [ldc / 32][c_panel_rows][32] (ldc % 32 == 0)
     // filled by head_fwd_launch: bytes from one k-step's columns to the next, and by how much a view shrinks per k-step
     long kstepA, kstepB; int remdecA, remdecB;

@@ -383,10 +383,12 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                     const bool ok = row_ok && colq + 32 * jp < p.store_cols - nw;
                     const unsigned off = ok ? c_lane_off + c_pair_off * jp : 0xFFFFFFFFu;
-                    // ordinary write-back stores: inside a training step (the caches full of other kernels' data) the
-                    // streaming forms (nt, write-through) made the whole launch 5-10 % slower, though they win when
-                    // the launch is repeated back to back
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, off, 0, 0);
+                    // the numerators (0.8 GB that nothing reads before the backward products) leave as non-temporal
+                    // stores: with the operands read as k-panel images that is 1.5 % faster inside the training step
+                    // (with row-major operands, whose loads asked for twice the lines, it was 5-10 % slower there);
+                    // the outputs of the standard epilogue, which the next kernel reads, stay write-back
+                    if ((MODE == 0 || MODE == 3) && p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, off, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, off, 0, 0);
                 }
             }
         }
@@ -410,6 +412,7 @@ constexpr int TIMING_PAIRS = 512;
 struct LaunchTiming { bool on = false; int n = 0; hipEvent_t ev[2 * TIMING_PAIRS] = {}; bool made = false; } g_timing;
 
 // diagnostic: k-panel images handed in beside the entry points' row-major operands (used when the sizes agree)
+int g_store_nt = 1;      // numerator stores non-temporal (diagnostic hook: 0 = write-back)
 struct PackedOverride { const bf16_t* Ap = nullptr; long a_rows = 0; const bf16_t* Bp = nullptr; long b_rows = 0; } g_packed;
 
 template <int WM, int WN, int TI, int NST>
@@ -418,6 +421,7 @@ int launch_geo(const HeadFwdArgs& a_in, hipStream_t st) {
     HeadFwdArgs a = a_in;
     if (!a.Ap && g_packed.Ap && g_packed.a_rows >= a.M) { a.Ap = g_packed.Ap; a.a_rows = g_packed.a_rows; }
     if (!a.Bp && g_packed.Bp && g_packed.b_rows >= a.N) { a.Bp = g_packed.Bp; a.b_rows = g_packed.b_rows; }
+    a.store_nt = g_store_nt;
     a.kstepA = a.kstepB = DBK * 2; a.remdecA = a.remdecB = DBK * 2;
     if (a.Ap) { a.A = a.Ap; a.lda = DBK; a.kstepA = a.a_rows * (DBK * 2); a.remdecA = 0; }
     if (a.Bp) { a.B = a.Bp; a.ldb = DBK; a.kstepB = a.b_rows * (DBK * 2); a.remdecB = 0; }
@@ -454,6 +458,7 @@ int launch_geo(const HeadFwdArgs& a_in, hipStream_t st) {
 
 }  // namespace
 
+extern "C" void capdecdbg_head_fwd_store_nt(int on) { g_store_nt = on; }
 extern "C" void capdecdbg_head_fwd_packed(const void* Ap, long a_rows, const void* Bp, long b_rows) {
     g_packed = PackedOverride{(const bf16_t*)Ap, a_rows, (const bf16_t*)Bp, b_rows};
 }
