@@ -231,7 +231,8 @@ class DecoderEngine:
         if self.opt.activation not in _ACTS:
             raise ValueError(f"activation must be one of {sorted(_ACTS)}")
         _lib.load()
-        self._bufs: Dict[str, torch.Tensor] = {}
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._fresh = set()
         self.cdt = self.opt.compute_dtype
         self.timer: Optional[KernelTimer] = None
         self._side: Optional[torch.cuda.Stream] = None
@@ -243,17 +244,27 @@ class DecoderEngine:
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name: str, shape, dtype, device, zero: bool = False) -> torch.Tensor:
+        """A named scratch tensor.  One allocation per (name, dtype), as large as the largest shape asked for so far: a
+        smaller request (the ragged last batch of an epoch) is a view of its beginning, not a second allocation."""
         shape = tuple(int(s) for s in shape)
-        key = (name, shape, dtype)
-        t = self._bufs.get(key)
-        if t is None or t.shape != shape or t.dtype != dtype or t.device != torch.device(device):
-            t = torch.empty(shape, dtype=dtype, device=device)
-            self._bufs[key] = t
-            if zero:
-                t.zero_()
-        elif zero:
+        n = math.prod(shape)
+        key = (name, dtype)
+        flat = self._bufs.get(key)
+        if flat is None or flat.numel() < n or flat.device != torch.device(device):
+            flat = torch.empty(max(n, 1), dtype=dtype, device=device)
+            self._bufs[key] = flat
+            self._fresh.add(key)
+        t = flat[:n].view(shape)
+        if zero:
             t.zero_()
         return t
+
+    def _was_fresh(self, name: str, dtype) -> bool:
+        """Whether the buffer was (re)allocated since this was last asked (contents that are written once need rewriting)."""
+        key = (name, dtype)
+        fresh = key in self._fresh
+        self._fresh.discard(key)
+        return fresh
 
     def _unit_affine(self, d, dev):
         key = ("unit_affine", d, str(dev))
@@ -490,9 +501,8 @@ class DecoderEngine:
             # W^T for the data gradient, made beside the forward product (the second stream is idle until the backward)
             kk_t = dl.shape[1] if dl.shape[1] <= V + W.head_pad_rows else V
             wt_shape = (d, (kk_t + 7) // 8 * 8)
-            fresh = ("head_w_t", wt_shape, cdt) not in self._bufs
             head_wt = self.buf("head_w_t", wt_shape, cdt, dev)
-            if fresh:
+            if self._was_fresh("head_w_t", cdt):
                 head_wt[:, V:].zero_()                    # the columns of the padding rows: never written again
             self._on_side_stream(lambda: ops.transpose(W.head_w, head_wt[:, :V]))
             head_wt_ready = torch.cuda.Event()

@@ -320,6 +320,33 @@ def test_trainer_two_adam_steps_match_reference():
         assert (state[k].cpu() - torch.from_numpy(g["after2." + k])).abs().max().item() <= 3e-6, k
 
 
+def test_ragged_last_batch_reuses_the_scratch_buffers():
+    """A smaller batch after a larger one (the last batch of an epoch) allocates nothing new -- its scratch tensors are
+    views of the existing ones -- and gives what a fresh model gives on that batch."""
+    sh = TINY
+    sd = helpers.make_state_dict(sh, seed=101)
+    img, sos, cap, labels = [t.to(DEV) for t in helpers.make_embeddings(sh, seed=202)]
+    nsmall = max(1, img.shape[0] // 2)
+    small = tuple(t[:nsmall].contiguous() for t in (img, sos, cap))
+    model = make_model(sh, sd, F32)
+    model.train()
+    model.caption_loss((img, sos, cap), labels)[0].backward()
+    eng = model.engine
+    held = {k: (v.data_ptr(), v.numel()) for k, v in eng._bufs.items() if torch.is_tensor(v)}
+    model.zero_grad()
+    loss = model.caption_loss(small, labels[:nsmall].contiguous())[0]
+    loss.backward()
+    after = {k: (v.data_ptr(), v.numel()) for k, v in eng._bufs.items() if torch.is_tensor(v)}
+    assert after == held, "the smaller batch changed the engine's allocations"
+    fresh = make_model(sh, sd, F32)
+    fresh.train()
+    want = fresh.caption_loss(small, labels[:nsmall].contiguous())[0]
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
+    for (k, p), (_, q) in zip(model.named_parameters(), fresh.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+
+
 def test_trainer_bf16_loss_decreases_and_tracks_f32():
     sh = TINY
     sd = helpers.make_state_dict(sh, seed=131)
