@@ -1608,7 +1608,7 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
     RowFold t = {-INFINITY, 0x7fffffff, -INFINITY, 0.f};
     if (m < M) {
         // FIN_UNROLL loads in flight before the first fold: the pass is a latency-bound read of np * 16 bytes per row
-        constexpr int FIN_UNROLL = 6;
+        constexpr int FIN_UNROLL = REF ? 13 : 6;      // (the 8-byte records: a thread's 25 slots of a 50k vocabulary in two batches)
         for (int sl = w; sl < np; sl += FIN_UNROLL * FIN_GROUPS) {
             f32x4 q[FIN_UNROLL];
 #pragma unroll
@@ -1710,12 +1710,15 @@ __global__ __launch_bounds__(256) void label_logit_kernel(const bf16_t* h, long 
 __device__ __forceinline__ long probs_index(long m, long v, long ld, long prows) {
     return prows ? ((v >> 5) * prows + m) * 32 + (v & 31) : m * ld + v;
 }
-__global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowflag, const bf16_t* h, long ldh, const bf16_t* W, long ldw,
+constexpr int FIX_ROWS = 64;
+__global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowflag, long M, const bf16_t* h, long ldh, const bf16_t* W, long ldw,
                                                             const float* bias, int d, int V, bf16_t* probs, long ld, long prows,
                                                             float* rowref, float* lse, float* rowloss) {
-    const long m = blockIdx.x;
-    if (!rowflag[m]) return;
     __shared__ float sm[4], ss[4];
+    // a workgroup looks after FIX_ROWS rows (normally none is flagged: the launch is 128 workgroups that read a flag each)
+    for (long m = (long)blockIdx.x * FIX_ROWS; m < min(M, ((long)blockIdx.x + 1) * FIX_ROWS); ++m) {
+    if (!rowflag[m]) continue;
+    __syncthreads();                                                  // the previous flagged row's shared sums are consumed
     const bf16_t* hr = h + m * ldh;
     auto logit = [&](int v) {
         const bf16_t* wr = W + (long)v * ldw;
@@ -1747,6 +1750,7 @@ __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowfla
     if (threadIdx.x == 0) {
         const float l = mx + logf((ss[0] + ss[1]) + (ss[2] + ss[3]));
         lse[m] = l; rowloss[m] = l - zl; rowref[m] = mx;
+    }
     }
 }
 
@@ -2366,7 +2370,7 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
     hipLaunchKernelGGL(ce_finalize_kernel<true>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, (const float*)rowref, labels, B, L, M, ws.np,
                        lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, LabelDot{}, ws.rowflag);
-    hipLaunchKernelGGL(ce_ref_fixup_kernel, dim3((unsigned)M), dim3(256), 0, st, (const int32_t*)ws.rowflag, (const bf16_t*)h, ldh,
+    hipLaunchKernelGGL(ce_ref_fixup_kernel, dim3((unsigned)((M + FIX_ROWS - 1) / FIX_ROWS)), dim3(256), 0, st, (const int32_t*)ws.rowflag, M, (const bf16_t*)h, ldh,
                        (const bf16_t*)W, ldw, bias, d, V, (bf16_t*)probs, ld_probs, prows, rowref, lse, ws.rowloss);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
     CAPDEC_LAUNCH_CHECK();
