@@ -369,6 +369,32 @@ def test_numerators_as_column_panel_image(B_, L, V, d, extra, hot_rows):
     close(c[11], a[11], 1e-3, "data gradient from the image")
 
 
+@pytest.mark.parametrize("akm", [False, True])
+@pytest.mark.parametrize("bkm", [False, True])
+@pytest.mark.parametrize("M,N,K,extra,with_ws", [
+    (264, 136, 96, 0, False),        # ragged last tile in both directions
+    (520, 72, 2080, 5, True),        # deep K through the workspace (split-K), rows to spare per panel
+    (33, 40, 64, 0, False),          # less than one tile
+    (1000, 768, 4096, 0, True),
+])
+def test_gemm_reads_a_column_panel_image(akm, bkm, M, N, K, extra, with_ws):
+    """capdec_gemm_desc.a_panel_rows: A given as the column-panel image [cols/32][R][32] of its stored matrix, in both
+    orientations and with either layout of B, against the same product on the matrix (same kernel, forced)."""
+    A = rnd(K, M, dtype=torch.bfloat16, seed=401) if akm else rnd(M, K, dtype=torch.bfloat16, seed=401)
+    B = rnd(K, N, dtype=torch.bfloat16, seed=402) if bkm else rnd(N, K, dtype=torch.bfloat16, seed=402)
+    rows, cols = A.shape
+    img = torch.full(((cols + 31) // 32, rows + extra, 32), float("nan"), device=DEV, dtype=torch.bfloat16)
+    padded = torch.zeros(rows, img.shape[0] * 32, device=DEV, dtype=torch.bfloat16)
+    padded[:, :cols] = A
+    img[:, :rows] = padded.view(rows, -1, 32).permute(1, 0, 2)
+    ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device=DEV) if with_ws else None
+    scale = rnd(M, seed=403)
+    want = scale[:, None] * ((A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t()))
+    got = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(img, B, got, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm, workspace=ws, row_scale=scale, a_panels=True)
+    close(got, want, 1.5e-2, "product from the image")
+
+
 @pytest.mark.parametrize("mode", [8, 9])
 @pytest.mark.parametrize("B_,L,V,d,with_bias,hot_rows", [
     (5, 8, 1111, 256, True, 0),
