@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("row_scale", c_void_p),
         ("kvec", c_void_p), ("kvec_out", c_void_p),
         ("a_panel_rows", c_long),
+        ("b_panels", c_void_p), ("b_panel_rows", c_long),
     ]
 
 
@@ -147,6 +148,7 @@ SIGNATURES = {
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_long, C.POINTER(KPanels), c_void_p, c_long, c_void_p]),
     "capdec_pack_kpanels": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "capdec_pack_kpanels_batched": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "capdec_logits_ce_bwd_from_probs": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_float,
                                                 c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "capdec_logits_ce_bwd_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_long, c_long,

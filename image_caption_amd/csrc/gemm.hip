@@ -2116,6 +2116,8 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     a.kv_cache = d->kv_cache; a.kv_q = d->kv_q; a.kv_d = d->kv_d; a.kv_B = d->kv_B; a.kv_H = d->kv_H; a.kv_hd = d->kv_hd;
     a.kv_smax = d->kv_smax; a.kv_s0 = d->kv_s0;
     a.kvec = (const bf16_t*)d->kvec; a.kvec_out = d->kvec_out; a.kvec_out_stride = 0;
+    CAPDEC_CHECK(!d->b_panels || (d->in_dtype == CAPDEC_BF16 && !d->b_kmajor && (d->K % 32) == 0 && d->b_panel_rows >= d->N && aligned16(d->b_panels)),
+                 "gemm: a k-panel image of B goes with a row-major bf16 B, K %% 32 == 0, b_panel_rows >= N, 16-byte aligned");
     if (d->a_panel_rows) {
         CAPDEC_CHECK(d->in_dtype == CAPDEC_BF16 && (d->K % 32) == 0 && d->a_panel_rows >= (d->a_kmajor ? d->K : d->M) && !d->bias && d->col_scale_n == 0 &&
                      d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual && !d->gate && !d->aux_out && !d->colsum && !d->kv_cache,
@@ -2196,6 +2198,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
         ha.mode = 1; ha.col_scale = a.col_scale_n > 0 ? a.col_scale : 1.f; ha.col_scale_n = a.col_scale_n;
         ha.relu = a.act == CAPDEC_ACT_RELU;
         ha.drop_thr = a.drop_thr; ha.drop_k0 = a.drop_k0; ha.drop_k1 = a.drop_k1; ha.drop_scale = a.drop_scale;
+        if (d->b_panels) { ha.Bp = (const bf16_t*)d->b_panels; ha.b_rows = d->b_panel_rows; }
         if (head_fwd_supported(ha)) return head_fwd_launch(ha, g_gemm_mode == 11 ? 0 : 1, (hipStream_t)stream);
     }
     // ... and those that add a dropped-out product to an f32 residual stream (the out_proj and linear2 forwards); shallow ones
@@ -2210,6 +2213,7 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
         ha.lda = a.lda; ha.ldb = a.ldb; ha.ldc = a.ldc; ha.ldr = a.ldr; ha.M = a.M; ha.N = a.N; ha.K = a.K; ha.store_cols = a.N;
         ha.mode = 2;
         ha.drop_thr = a.drop_thr; ha.drop_k0 = a.drop_k0; ha.drop_k1 = a.drop_k1; ha.drop_scale = a.drop_scale;
+        if (d->b_panels) { ha.Bp = (const bf16_t*)d->b_panels; ha.b_rows = d->b_panel_rows; }
         if (head_fwd_supported(ha)) return head_fwd_launch(ha, (g_gemm_mode == 11 || (g_gemm_mode == 0 && small_residual)) ? 0 : 1, (hipStream_t)stream);
     }
     // straight-line epilogue: bias / column scale / ReLU / dropout only, every lane's 16-byte group of columns

@@ -324,7 +324,9 @@ __global__ void cast_kernel(const TS* s, TD* d, long n) {
 // 16-byte chunk; a wave's store covers 8 panels x 128 consecutive bytes (2 rows).  Optionally the plain bf16 cast as well.
 template <typename TS>
 __global__ __launch_bounds__(256) void pack_kpanels_kernel(const TS* src, long ld_src, long rows, int K, bf16_t* panels, long panel_rows,
-                                                            bf16_t* rowmajor, long ld_rm) {
+                                                            bf16_t* rowmajor, long ld_rm, long src_batch_stride, long panels_batch_stride) {
+    src += (long)blockIdx.z * src_batch_stride;            // matrix z of a batch (one matrix: z = 0)
+    panels += (long)blockIdx.z * panels_batch_stride;
     const int c = threadIdx.x & 31;                        // 8-element chunk inside the block's 256 columns
     const int k = blockIdx.x * 256 + c * 8;
     if (k >= K) return;
@@ -798,8 +800,25 @@ extern "C" int capdec_cast(const void* src, int src_dtype, void* dst, int dst_dt
     return CAPDEC_OK;
 }
 
+static int pack_kpanels_impl(const void* src, int src_dtype, long rows, int K, long ld_src, long src_batch_stride,
+                            void* panels, long panel_rows, long panels_batch_stride, int batch, void* rowmajor, long ld_rm, void* stream);
+
 extern "C" int capdec_pack_kpanels(const void* src, int src_dtype, long rows, int K, long ld_src,
                                    void* panels, long panel_rows, void* rowmajor, long ld_rm, void* stream) {
+    return pack_kpanels_impl(src, src_dtype, rows, K, ld_src, 0, panels, panel_rows, 0, 1, rowmajor, ld_rm, stream);
+}
+
+extern "C" int capdec_pack_kpanels_batched(const void* src, int src_dtype, long rows, int K, long ld_src, long src_batch_stride,
+                                           void* panels, long panel_rows, long panels_batch_stride, int batch, void* stream) {
+    const long per16 = src_dtype == CAPDEC_F32 ? 4 : 8;
+    CAPDEC_CHECK(batch >= 0 && batch <= 65535 && (src_batch_stride % per16) == 0 && (panels_batch_stride % 8) == 0,
+                 "pack_kpanels_batched: the matrices and their images must lie whole 16-byte units apart (batch <= 65535)");
+    if (batch == 0) return CAPDEC_OK;
+    return pack_kpanels_impl(src, src_dtype, rows, K, ld_src, src_batch_stride, panels, panel_rows, panels_batch_stride, batch, nullptr, 0, stream);
+}
+
+static int pack_kpanels_impl(const void* src, int src_dtype, long rows, int K, long ld_src, long src_batch_stride,
+                            void* panels, long panel_rows, long panels_batch_stride, int batch, void* rowmajor, long ld_rm, void* stream) {
     CAPDEC_CHECK(src && panels, "pack_kpanels: null pointer");
     CAPDEC_CHECK(src_dtype == CAPDEC_F32 || src_dtype == CAPDEC_BF16, "pack_kpanels: bad dtype");
     const long per16 = src_dtype == CAPDEC_F32 ? 4 : 8;
@@ -812,12 +831,14 @@ extern "C" int capdec_pack_kpanels(const void* src, int src_dtype, long rows, in
     // the grid's y extent is limited to 65535: rows beyond that go to further launches
     for (long r0 = 0; r0 < rows; r0 += 65535L * 16) {
         const long nr = rows - r0 < 65535L * 16 ? rows - r0 : 65535L * 16;
-        dim3 g((unsigned)((K + 255) / 256), (unsigned)((nr + 15) / 16)), b(256);
+        dim3 g((unsigned)((K + 255) / 256), (unsigned)((nr + 15) / 16), (unsigned)batch), b(256);
         bf16_t* rm = rowmajor ? (bf16_t*)rowmajor + r0 * ld_rm : nullptr;
         if (src_dtype == CAPDEC_F32)
-            hipLaunchKernelGGL(pack_kpanels_kernel<float>, g, b, 0, st, (const float*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm);
+            hipLaunchKernelGGL(pack_kpanels_kernel<float>, g, b, 0, st, (const float*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm,
+                               src_batch_stride, panels_batch_stride);
         else
-            hipLaunchKernelGGL(pack_kpanels_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm);
+            hipLaunchKernelGGL(pack_kpanels_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)src + r0 * ld_src, ld_src, nr, K, (bf16_t*)panels + r0 * 32, panel_rows, rm, ld_rm,
+                               src_batch_stride, panels_batch_stride);
     }
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;

@@ -324,6 +324,7 @@ class CaptionTrainer:
         # one launch over the flat buffer on a single GPU; with several, one launch per all-reduce bucket, so
         # that the update of the vocabulary matrix overlaps the reduction of the last bucket
         self.reducer.drain(adam)
+        st.refresh_block_panels()      # (a stack only: the images of the blocks' matrices follow the update)
         return out
 
     @torch.no_grad()

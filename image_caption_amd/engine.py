@@ -123,6 +123,16 @@ class ParamStore:
         # refresh_head_panels() after every change of the parameters
         self.head_panels = (torch.zeros(ops.kpanel_shape(V, d), dtype=torch.bfloat16, device=device)
                             if compute_dtype == torch.bfloat16 and d % 32 == 0 else None)
+        # ... and of the blocks' four matrices, for a stack (its forward products run over every row: large row-major
+        # products that read the image 5 % faster; for a single block's short products the refresh would cost more than
+        # it returns).  block_panels[name][z] is the image of block n_blocks - 1 - z's matrix: the blocks lie in that
+        # order, a constant number of elements apart, so one batched launch per matrix kind refreshes them all.
+        self.block_panels = {}
+        if compute_dtype == torch.bfloat16 and geo.n_blocks > 1 and d % 32 == 0 and ff % 32 == 0:
+            for name, fn in BLOCK_PARAM_SHAPES:
+                if name in MATRIX_KEYS:
+                    rows, K = fn(d, ff)
+                    self.block_panels[name] = torch.zeros((geo.n_blocks,) + ops.kpanel_shape(rows, K), dtype=torch.bfloat16, device=device)
 
     def view(self, buf: torch.Tensor, key: str) -> torch.Tensor:
         o, shape = self.offsets[key]
@@ -136,10 +146,19 @@ class ParamStore:
         if self.shadow is not self.w:
             ops.cast(self.w, self.shadow)
         self.refresh_head_panels()
+        self.refresh_block_panels()
 
     def refresh_head_panels(self):
         if self.head_panels is not None:
             ops.pack_kpanels(self.compute(HEAD_W), self.head_panels)
+
+    def refresh_block_panels(self):
+        """The images of the blocks' matrices from the current shadow: four launches, whatever the number of blocks."""
+        nb = self.geo.n_blocks
+        for name, panels in self.block_panels.items():
+            first, shape = self.offsets[block_key(nb - 1, name, nb)]              # the block stored first
+            stride = self.offsets[block_key(nb - 2, name, nb)][0] - first
+            ops.pack_kpanels_batched(self.shadow, first, shape[0], shape[1], nb, stride, panels)
 
     def load(self, state: Dict[str, torch.Tensor]):
         for key, shape, _ in self.layout:
@@ -183,6 +202,7 @@ class KernelTimer:
 
 
 IN_PROJ_MASTER = "self_attn.in_proj_weight.f32"       # block 0 only: the f32 parameter behind the compute-dtype matrix
+PANELS = ".k_panels"                                  # suffix of the optional k-panel image of a block matrix ([K/32, rows, 32] bf16)
 
 
 class _Weights:
@@ -207,6 +227,8 @@ def weights_from_store(store: ParamStore) -> _Weights:
             b[name] = store.compute(key) if name in MATRIX_KEYS else store.param(key)
         if i == 0:
             b[IN_PROJ_MASTER] = store.param(block_key(0, "self_attn.in_proj_weight", geo.n_blocks))
+        for name, panels in store.block_panels.items():
+            b[name + PANELS] = panels[geo.n_blocks - 1 - i]
         blocks.append(b)
     return _Weights(blocks, store.compute(HEAD_W), store.param(HEAD_B), store.head_pad_rows, store.head_panels)
 
@@ -323,9 +345,12 @@ class DecoderEngine:
         scale = hd ** -0.5
         # in_proj: the block's own, or the pair with norm1's affine folded in (h1 then holds the normalised rows)
         in_w, in_b = in_proj if in_proj is not None else (w["self_attn.in_proj_weight"], w["self_attn.in_proj_bias"])
+        # images of the matrices (a stack's parameter store keeps them): read by the products large enough for the persistent kernel
+        img = (lambda name: w.get(name + PANELS)) if self.opt.head_k_panels else (lambda name: None)
         with self._span("block_qkv_fwd"):
             if q_start == 0:
-                ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d)
+                ops.gemm(h1, in_w, qkv, bias=in_b, col_scale=scale, col_scale_n=d,
+                         b_panels=img("self_attn.in_proj_weight") if in_proj is None else None)
             else:
                 ops.gemm(h1, in_w[d:], qkv[:, d:], bias=in_b[d:])
                 ops.gemm(h1[r0:], in_w[:d], qkv[r0:, :d], bias=in_b[:d], col_scale=scale, col_scale_n=d)
@@ -338,7 +363,8 @@ class DecoderEngine:
         x_mid = self.buf(f"x_mid.{i}", (Mt, d), torch.float32, dev)
         k_r1 = self._keys(4 * i + 1, step, train)
         with self._span("block_out_proj_fwd"):
-            ops.gemm(attn_o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], drop=k_r1, residual=x_in[r0:])
+            ops.gemm(attn_o[r0:], w["self_attn.out_proj.weight"], x_mid, bias=w["self_attn.out_proj.bias"], drop=k_r1, residual=x_in[r0:],
+                     b_panels=img("self_attn.out_proj.weight"))
         h2 = self.buf(f"h2.{i}", (Mt, d), cdt, dev)
         mean2 = self.buf(f"mean2.{i}", (Mt,), torch.float32, dev)
         rstd2 = self.buf(f"rstd2.{i}", (Mt,), torch.float32, dev)
@@ -352,8 +378,9 @@ class DecoderEngine:
         x_out = self.buf(f"x_out.{i}", (Mt, d), torch.float32, dev)
         k_r2 = self._keys(4 * i + 3, step, train)
         with self._span("block_mlp_fwd"):
-            ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation], drop=k_h, aux_out=z1)
-            ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid)
+            ops.gemm(h2, w["linear1.weight"], a1, bias=w["linear1.bias"], act=_ACTS[self.opt.activation], drop=k_h, aux_out=z1,
+                     b_panels=img("linear1.weight"))
+            ops.gemm(a1, w["linear2.weight"], x_out, bias=w["linear2.bias"], drop=k_r2, residual=x_mid, b_panels=img("linear2.weight"))
         sv.update(x_in=x_in, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x_mid=x_mid, h2=h2,
                   mean2=mean2, rstd2=rstd2, a1=a1, z1=z1, q_start=q_start, keys=(k_attn, k_r1, k_h, k_r2),
                   folded=in_proj is not None)

@@ -161,7 +161,7 @@ def _ld(t: torch.Tensor) -> int:
 def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, bias=None, col_scale=1.0, col_scale_n=0,
          act=ACT_NONE, drop: Dropout = NO_DROPOUT, residual=None, accumulate=False, gate=None, gate_mode=GATE_NONE,
          gate_drop: Dropout = NO_DROPOUT, aux_out=None, colsum=None, kv_cache=None, kv_geom=None, workspace=None, row_scale=None, kvec=None, kvec_out=None,
-         a_panels=False):
+         a_panels=False, b_panels=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  A is [M,K] (or [K,M] if a_kmajor),
     B is [N,K] (or [K,N] if b_kmajor).  a_panels: A is the column-panel image [cols/32, R, 32] of that stored matrix
     (M and K must then be given)."""
@@ -182,6 +182,11 @@ def gemm(A, B, Cout, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, 
     d.lda, d.ldb, d.ldc = (32 if a_panels else _ld(A)), _ld(B), _ld(Cout)
     if a_panels:
         d.a_panel_rows = A.shape[1]
+    if b_panels is not None:               # k-panel image of the row-major B, for the kernels that read it
+        require_cuda(b_panels)
+        assert not b_kmajor and b_panels.dtype == torch.bfloat16 and b_panels.is_contiguous() and b_panels.dim() == 3
+        assert b_panels.shape[0] * 32 == K and b_panels.shape[1] >= N and b_panels.shape[2] == 32
+        d.b_panels, d.b_panel_rows = ptr(b_panels), b_panels.shape[1]
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
     d.in_dtype, d.out_dtype = dtype_code(A), dtype_code(Cout)
     d.bias = ptr(bias)
@@ -300,6 +305,18 @@ def pack_kpanels(src, panels, rowmajor=None):
     assert src.stride(1) == 1 and (rowmajor is None or (rowmajor.dtype == torch.bfloat16 and rowmajor.shape == src.shape and rowmajor.stride(1) == 1))
     check(_lib.load().capdec_pack_kpanels(ptr(src), dtype_code(src), rows, K, _ld(src), ptr(panels), panels.shape[1],
                                           ptr(rowmajor), _ld(rowmajor) if rowmajor is not None else 0, _st()), "capdec_pack_kpanels")
+    return panels
+
+
+def pack_kpanels_batched(src_flat, first, rows, K, batch, src_batch_stride, panels):
+    """Images of `batch` row-major [rows, K] matrices that lie src_batch_stride elements apart in the 1-D tensor src_flat,
+    the first at element `first`: panels[z] ([batch, K/32, rows, 32] bf16) = image of matrix z."""
+    require_cuda(src_flat, panels)
+    assert src_flat.dim() == 1 and src_flat.is_contiguous() and panels.is_contiguous() and panels.dtype == torch.bfloat16
+    assert tuple(panels.shape) == (batch, K // 32, rows, 32) and first + (batch - 1) * src_batch_stride + rows * K <= src_flat.numel()
+    check(_lib.load().capdec_pack_kpanels_batched(src_flat.data_ptr() + first * src_flat.element_size(), dtype_code(src_flat), rows, K, K,
+                                                  src_batch_stride, ptr(panels), rows, panels[0].numel(), batch, _st()),
+          "capdec_pack_kpanels_batched")
     return panels
 
 

@@ -175,6 +175,10 @@ typedef struct {
      * ((c / 32) * R + r) * 32 + c % 32; lda unused): what capdec_logits_ce_fwd_ref writes with capdec_kpanels.probs_rows.
      * A row-major A read in 32-deep steps then comes in whole 128-byte lines. */
     long a_panel_rows;
+    /* optional k-panel image of a row-major B ([K / 32][b_panel_rows >= N][32] bf16, capdec_pack_kpanels; NULL: none).  B
+     * itself must still be given: kernels that can read the image do (large row-major products on the persistent
+     * kernel, 5 % faster), the others read B.  Results are bit-identical. */
+    const void* b_panels; long b_panel_rows;
 } capdec_gemm_desc;
 
 int capdec_gemm_bias_act(const capdec_gemm_desc* desc, void* stream);
@@ -262,6 +266,11 @@ typedef struct {
  * rowmajor (optional, bf16 [rows, ld_rm]) receives the plain cast of src in the same pass (capdec_cast). */
 int capdec_pack_kpanels(const void* src, int src_dtype, long rows, int K, long ld_src,
                         void* panels, long panel_rows, void* rowmajor, long ld_rm, void* stream);
+/* The same for `batch` matrices of one shape in one launch (the same weight of every block of a stack, which lie a
+ * constant number of elements apart in a flat parameter buffer): matrix z starts src_batch_stride elements after matrix
+ * z - 1, its image panels_batch_stride elements after the previous image.  No row-major copy. */
+int capdec_pack_kpanels_batched(const void* src, int src_dtype, long rows, int K, long ld_src, long src_batch_stride,
+                                void* panels, long panel_rows, long panels_batch_stride, int batch, void* stream);
 
 int capdec_logits_ce_fwd(const void* h, const void* W, const float* bias, int dtype,
                          long M, int V, int d, long ldh, long ldw,

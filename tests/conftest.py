@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def gemm_mode():
+    """Forces one bf16 kernel geometry (diagnostic hook of the library); restored afterwards."""
+    import ctypes
+
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
+    lib.capdecdbg_gemm_mode.restype = None
+    yield lib.capdecdbg_gemm_mode
+    lib.capdecdbg_gemm_mode(0)

@@ -49,17 +49,6 @@ def test_gemm_layouts(dtype, tol, akm, bkm, M, N, K):
     close(out, ref, tol, "gemm")
 
 
-@pytest.fixture
-def gemm_mode():
-    """Forces one bf16 kernel geometry (diagnostic hook of the library); restored afterwards."""
-    import ctypes
-    lib = _lib.load()
-    lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
-    lib.capdecdbg_gemm_mode.restype = None
-    yield lib.capdecdbg_gemm_mode
-    lib.capdecdbg_gemm_mode(0)
-
-
 # 1 register-staged, 2 ring 128x128, 3 ring 256x128 (8 waves), 4 ring 256x128 (4 waves of 128x64),
 # 5 ring 256x256 (8 waves of 128x64; plain products only), 6 pipelined 256x256 with 4 waves of 128x128 (plain products
 # only), 7 pipelined 256x128 with 4 waves of 128x64 (plain products in any layout, row-major with every epilogue)
@@ -393,6 +382,36 @@ def test_gemm_reads_a_column_panel_image(akm, bkm, M, N, K, extra, with_ws):
     got = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(img, B, got, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm, workspace=ws, row_scale=scale, a_panels=True)
     close(got, want, 1.5e-2, "product from the image")
+
+
+def test_pack_kpanels_batched_and_gemm_b_image(gemm_mode):
+    """Images of several equally shaped matrices of a flat buffer in one launch; a large row-major product given the image
+    of its B returns the same bits, on both geometries of the persistent kernel, with either epilogue, and by default."""
+    rows, K, batch, stride, first = 200, 96, 3, 200 * 96 + 64, 128
+    flat = rnd(first + batch * stride, dtype=torch.bfloat16, seed=501)
+    panels = torch.full((batch,) + ops.kpanel_shape(rows, K), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.pack_kpanels_batched(flat, first, rows, K, batch, stride, panels)
+    for z in range(batch):
+        mat = flat[first + z * stride: first + z * stride + rows * K].view(rows, K)
+        assert torch.equal(panels[z], mat.view(rows, K // 32, 32).permute(1, 0, 2))
+    for M, N, K2, mode in ((515, 640, 768, 10), (515, 640, 768, 11), (8192, 2048, 768, 0)):
+        x = rnd(M, K2, dtype=torch.bfloat16, seed=502)
+        w = rnd(N, K2, dtype=torch.bfloat16, scale=0.05, seed=503)
+        b = rnd(N, seed=504)
+        res = rnd(M, N, seed=505)
+        wp = ops.pack_kpanels(w, torch.empty(ops.kpanel_shape(N + 3, K2), device=DEV, dtype=torch.bfloat16).fill_(float("nan")))
+        drop = ops.dropout_keys(7, 1, 2, 0.1)
+        outs = []
+        for img in (None, wp):
+            y1 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            y2 = torch.full((M, N), float("nan"), device=DEV)
+            gemm_mode(mode)
+            ops.gemm(x, w, y1, bias=b, act=_lib.ACT_RELU, drop=drop, b_panels=img)
+            ops.gemm(x, w, y2, bias=b, drop=drop, residual=res, b_panels=img)
+            gemm_mode(0)
+            outs.append((y1, y2))
+        assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1], outs[1][1])
+        assert not bool(torch.isnan(outs[0][1]).any())
 
 
 @pytest.mark.parametrize("mode", [8, 9])

@@ -320,6 +320,38 @@ def test_trainer_two_adam_steps_match_reference():
         assert (state[k].cpu() - torch.from_numpy(g["after2." + k])).abs().max().item() <= 3e-6, k
 
 
+def test_stack_trainer_with_block_weight_images(gemm_mode):
+    """A two-block stack trained through the parameter store: the images of the blocks' matrices it keeps (refreshed by a
+    batched launch after every update) are what the persistent kernel reads, and leave every result as it is without them."""
+    from image_caption_amd.engine import PANELS
+    geo = dict(d_model=256, nhead=2, dim_feedforward=512, vocab=1003, P=20, L=8, B=6)
+    finals = []
+    for use in (True, False):
+        torch.manual_seed(5)
+        opts = EngineOptions(compute_dtype=BF16, mask_mode="prefix_causal", head_k_panels=use)
+        model = TransformerDecoder(geo["d_model"], geo["nhead"], 6, geo["dim_feedforward"], 0.1, geo["vocab"], n_blocks=2, options=opts).to(DEV)
+        model.train()
+        tr = CaptionTrainer(model, lr=1e-3, weight_decay=0.01)
+        assert all(("linear1.weight" + PANELS) in b for b in tr.W.blocks)
+        g = torch.Generator().manual_seed(6)
+        img = torch.randn(geo["B"], geo["P"], geo["d_model"], generator=g).to(DEV)
+        sos = torch.randn(geo["B"], 1, geo["d_model"], generator=g).to(DEV)
+        cap = torch.randn(geo["B"], geo["L"], geo["d_model"], generator=g).to(DEV)
+        labels = torch.randint(0, geo["vocab"], (geo["B"], geo["L"]), generator=g).to(DEV)
+        gemm_mode(10)                                     # every eligible product on the persistent kernel, whatever its size
+        losses = [tr.step((img, sos, cap), labels)[0].item() for _ in range(3)]
+        gemm_mode(0)
+        # the images follow the updates: block z of the stored order is block n - 1 - z
+        for name, panels in tr.store.block_panels.items():
+            for i in range(2):
+                wmat = tr.W.blocks[i][name]
+                assert torch.equal(panels[1 - i], wmat.view(wmat.shape[0], -1, 32).permute(1, 0, 2)), (name, i)
+        finals.append((losses, {k: v.clone() for k, v in model.state_dict().items()}))
+    assert finals[0][0] == finals[1][0]
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+
+
 def test_ragged_last_batch_reuses_the_scratch_buffers():
     """A smaller batch after a larger one (the last batch of an epoch) allocates nothing new -- its scratch tensors are
     views of the existing ones -- and gives what a fresh model gives on that batch."""
