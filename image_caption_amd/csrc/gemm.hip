@@ -2072,7 +2072,9 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     // Plain deep-K products on 256x256 tiles whose last round of workgroups would leave most CUs idle (the vocabulary
     // weight gradient: 591 tiles on 256 CUs = 2.3 rounds billed as 3): the M-tiles of that last round are cut off and
     // run as a second, split-K product through the workspace -- 2 rounds + 1/3 instead of 3.
-    if (d->in_dtype == CAPDEC_BF16 && g_gemm_mode == 0 && d->workspace && d->K >= 2048 && !d->bias && d->col_scale_n == 0 &&
+    // (not with a vector column whose k range has to be cut to fit the kernel's LDS: that product is split along K below)
+    const bool kvec_deep = d->kvec && d->kvec_out && d->K > 8192;
+    if (d->in_dtype == CAPDEC_BF16 && g_gemm_mode == 0 && d->workspace && d->K >= 2048 && !d->bias && d->col_scale_n == 0 && !kvec_deep &&
         d->act == CAPDEC_ACT_NONE && d->drop.p <= 0.f && !d->residual && !d->gate && !d->aux_out && !d->colsum && !d->kv_cache &&
         ((d->K % 32) == 0 || (d->a_kmajor && d->b_kmajor))) {
         const long tmw = (d->M + 255) / 256, tnw = (d->N + 255) / 256, wide = tmw * tnw, rem = wide % 256;
@@ -2135,7 +2137,10 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
     const int nkt = (a.K + BK - 1) / BK;
     const bool plain = !a.bias && a.col_scale_n == 0 && a.act == CAPDEC_ACT_NONE && !a.drop_thr && !a.residual &&
                        a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache;
-    if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && tiles <= 512 && nkt >= 32) {
+    // A vector column (kvec) rides on the pipelined kernel only while a workgroup's k range of the vector fits its LDS (8192
+    // values): a deeper product with both operands reduction-major is cut along K for that, whatever its tile count
+    const bool kvec_split = d->in_dtype == CAPDEC_BF16 && plain && d->workspace && kvec_deep && a.a_kmajor && a.b_kmajor && g_gemm_mode == 0;
+    if (d->in_dtype == CAPDEC_BF16 && plain && d->workspace && (tiles <= 512 || kvec_split) && nkt >= 32) {
         // the split that best fills whole rounds of the 512 resident workgroups (two per CU), counted in the
         // tiles of the kernel that will run; the smallest such split, since every slab is written and re-read
         const bool ring_ok = (a.K % 32) == 0 || (a.a_kmajor && a.b_kmajor);
@@ -2160,6 +2165,14 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             if (wide_possible && n < WIDE_MIN_WGS) continue;
             const double eff = (double)n / (double)((n + resident - 1) / resident * resident);
             if (eff > best + 0.03) { best = eff; split = sp; }
+        }
+        const long nk32 = (a.K + DBK - 1) / DBK;
+        if (kvec_split && (nk32 + split - 1) / split * DBK > 8192) {
+            // the fewest further slabs whose k ranges (whole 32-deep steps) hold at most 8192 values
+            long fit = 0;
+            for (long sp = split + 1; sp <= maxsp && !fit; ++sp)
+                if ((nk32 + sp - 1) / sp * DBK <= 8192) fit = sp;
+            if (fit) split = fit;                       // else: the workspace does not hold that many slabs, and the vector product takes its own pass
         }
         const long slab = (long)a.M * a.N;
         if (split > 1 && ws_bytes >= split * slab * 4) {

@@ -519,7 +519,7 @@ class DecoderEngine:
         # 32-deep steps as whole lines.  Only where both backward products run on the pipelined 256x256 kernel anyway and
         # the bias gradient rides on the weight-gradient product (nothing else reads the numerators).
         dl_img = (by_row and self.opt.dl_panels and self.opt.ce_bias_in_wgrad and not self.opt.dgrad_transposed_weights and
-                  2048 <= Mh <= 8192 and Mh % 256 == 0 and dl.shape[1] <= V + W.head_pad_rows)
+                  Mh >= 2048 and Mh % 256 == 0 and dl.shape[1] <= V + W.head_pad_rows)
         self.last_dl_panels = dl_img
         if dl_img:
             dl = dl.view(dl.shape[1] // 32, Mh, 32)
@@ -547,7 +547,10 @@ class DecoderEngine:
         dH = self.buf("ce_dH", (Mh, d), torch.float32, dev)
         gW, gb = grads[HEAD_W], grads[HEAD_B]
         bws = self.buf("ce_bwd_ws", (max(ops.logits_ce_bwd_workspace(Mh, slab), ops.colsum_workspace(Mh, V)),), torch.uint8, dev)
-        hws = self.buf("head_splitk_ws", (8 * Mh * d * 4,), torch.uint8, dev)
+        # split-K slabs of the data gradient (8 of them) or, past 8192 scored rows, of the weight gradient with its bias column
+        # (one per 8192 rows: the kernel keeps a slab's row factors in LDS) + that column's slabs
+        wg_slabs = (Mh + 8191) // 8192
+        hws = self.buf("head_splitk_ws", (max(8 * Mh * d * 4, (wg_slabs * V * d * 4 + 32 * V * 4 + 64) if wg_slabs > 1 else 0),), torch.uint8, dev)
         first = True
         if by_row:
             # d(logits) = rowscale[m] * numerators (label column patched): no pass over the [Mh, V] array but the products'
@@ -557,7 +560,7 @@ class DecoderEngine:
             rowscale_lp = self.buf("ce_rowscale_lp", (Mh,), cdt, dev)
             with self._span("ce_bwd_prepare"):
                 ops.logits_ce_bwd_ref_prepare(dl, V, h, labels, B, L, lse, rowref, gscale, hs, rowscale, rowscale_lp)
-            if self.opt.ce_bias_in_wgrad and Mh <= 8192:        # the kernel keeps the row factors of its k range (all Mh rows) in LDS
+            if self.opt.ce_bias_in_wgrad:        # (the kernel keeps the row factors of a workgroup's k range in LDS: past 8192 rows the product is cut along them)
                 # the bias gradient is one more column of the weight-gradient product (numerators^T . rowscale): formed by that
                 # product's kernel on the way instead of by a pass over the numerators
                 with self._span("head_wgrad_slab"):

@@ -525,6 +525,23 @@ def test_gemm_vector_column(M, N, K, with_ws):
     close(out3, A.float().sum(0), 2e-3, "column sums as a vector column")
 
 
+def test_gemm_vector_column_cuts_deep_products():
+    """A product too deep for the vector's k range to fit the kernel (K > 8192) and with too many tiles for split-K to be
+    chosen for its own sake: given a workspace it is cut along K so that the vector column still rides along."""
+    M, N, K = 8192, 2048, 16384
+    A = rnd(K, M, dtype=torch.bfloat16, seed=590)
+    B = rnd(K, N, dtype=torch.bfloat16, scale=0.1, seed=591)
+    v = rnd(K, dtype=torch.bfloat16, seed=592)
+    ws = torch.empty(2 * M * N * 4 + 32 * M * 4 + 64, dtype=torch.uint8, device=DEV)
+    C0 = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A, B, C0, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True)
+    C1 = torch.full((M, N), float("nan"), device=DEV)
+    out = torch.full((M,), float("nan"), device=DEV)
+    ops.gemm(A, B, C1, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, workspace=ws, kvec=v, kvec_out=out)
+    close(C1, C0, 1e-5, "product in two slabs")
+    close(out, A.float().t() @ v.float(), 2e-3, "vector column")
+
+
 def test_persistent_logits_ce_forward_repeats_exactly(gemm_mode):
     """200 launches of each geometry on one input give bit-identical numerators and partial sums: the operand ring's
     waits are sufficient on every tile of every launch (a stage read before it had landed shows up here)."""

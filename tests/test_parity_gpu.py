@@ -352,6 +352,35 @@ def test_stack_trainer_with_block_weight_images(gemm_mode):
         assert torch.equal(finals[0][1][k], finals[1][1][k]), k
 
 
+def test_head_backward_past_8192_scored_rows():
+    """More than 8192 scored rows (a per-GPU batch above 256): the weight gradient is cut along the rows so that the bias
+    column still rides on it, and d(logits) stays a column-panel image.  Against the same step with a separate bias pass over
+    a row-major d(logits), and against the f32 mode."""
+    d, H, ff, V, P, L, B = 256, 2, 512, 1003, 3, 32, 288            # 9216 scored rows
+    g = torch.Generator().manual_seed(11)
+    img, sos, cap = (torch.randn(B, n, d, generator=g).to(DEV) for n in (P, 1, L))
+    labels = torch.randint(0, V, (B, L), generator=g).to(DEV)
+    grads = {}
+    for name, opts in (("image", EngineOptions(compute_dtype=BF16)),
+                       ("matrix", EngineOptions(compute_dtype=BF16, dl_panels=False, ce_bias_in_wgrad=False)),
+                       ("f32", EngineOptions(compute_dtype=F32))):
+        torch.manual_seed(12)
+        model = TransformerDecoder(d, H, 6, ff, 0.0, V, options=opts).to(DEV)
+        model.train()
+        tr = CaptionTrainer(model, lr=0.0, weight_decay=0.0)            # the flat parameter store (zero rows behind the vocabulary matrix)
+        loss_sum, _, rows = tr.step((img, sos, cap), labels)
+        if name == "image":
+            assert model.engine.last_dl_panels and model.engine.last_by_row
+        grads[name] = (loss_sum.item() / rows, {k: v.clone() for k, v in tr.grads.items()})
+    assert abs(grads["image"][0] - grads["matrix"][0]) <= 1e-6 * abs(grads["matrix"][0])
+    assert abs(grads["image"][0] - grads["f32"][0]) <= 1e-2 * abs(grads["f32"][0])
+    for k, gi in grads["image"][1].items():
+        gm, gf = grads["matrix"][1][k], grads["f32"][1][k]
+        assert (gi - gm).abs().max().item() <= 2e-3 * gm.abs().max().item() + 1e-12, k
+        cos = torch.nn.functional.cosine_similarity(gi.flatten().double(), gf.flatten().double(), dim=0).item()
+        assert cos >= 0.9985, (k, cos)
+
+
 def test_ragged_last_batch_reuses_the_scratch_buffers():
     """A smaller batch after a larger one (the last batch of an epoch) allocates nothing new -- its scratch tensors are
     views of the existing ones -- and gives what a fresh model gives on that batch."""
