@@ -201,6 +201,10 @@ def load():
         lib.capdecdbg_head_fwd_store_nt.argtypes = [c_int]
         lib.capdecdbg_head_fwd_store_nt.restype = None
         lib.capdecdbg_head_fwd_store_nt(int(os.environ["CAPDEC_HEAD_FWD_STORE_NT"]))
+    if os.environ.get("CAPDEC_ROUTE_SMALL") and hasattr(lib, "capdecdbg_gemm_route_small"):      # diagnostic: 0 = without the short-product routing rules
+        lib.capdecdbg_gemm_route_small.argtypes = [c_int]
+        lib.capdecdbg_gemm_route_small.restype = None
+        lib.capdecdbg_gemm_route_small(int(os.environ["CAPDEC_ROUTE_SMALL"]))
     geo = os.environ.get("CAPDEC_HEAD_FWD_GEOMETRY")      # diagnostic: tile geometry of the persistent logits+CE forward (0 / 1)
     if geo is not None and hasattr(lib, "capdecdbg_head_fwd_geometry"):
         lib.capdecdbg_head_fwd_geometry.argtypes = [c_int]

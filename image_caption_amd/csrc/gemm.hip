@@ -1390,6 +1390,7 @@ thread_local bool t_kvec_done = false;      // the last launch_gemm formed A . k
 constexpr long WIDE_MIN_WGS = 218;   // 256x256 tiles (one workgroup per CU) pay off from 85 % of the 256 CUs busy
 int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every ring launch (lowers the workgroups per CU)
 long g_dbg_a_panel = 0;  // diagnostic: the next 256x256 pipelined launches read A as a column-panel image with this many rows per panel
+int g_route_small = 1;   // the two routing rules for short products below (diagnostic hook capdecdbg_gemm_route_small: 0 = without)
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 pipelined 256x256, 7 pipelined 256x128)
 
 template <int EPI>
@@ -1430,7 +1431,14 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
         if (EPI == EPI_STD && ring_ok && a.K >= 1536 && wide_tiles * split >= WIDE_MIN_WGS) {
             if (wide_tiles >= 16) kern = KERN_QUAD;
             else if (a.K >= 2048) kern = KERN_WIDE;
+            // slabs of fewer than 40 k-steps (a block's weight gradients over the 8192 scored rows of a batch of 256, cut into
+            // ten slabs): the 8-wave ring, whose tile has less to fill and drain (53 -> 47 us alone)
+            if (g_route_small && kern == KERN_QUAD && a.K >= 2048 && a.K / split < 1280) kern = KERN_WIDE;
         }
+        // a single round of tall tiles over a reduction of 48 to 128 k-steps with a reduction-major second operand (linear1's
+        // data gradient on those rows): the pipelined 256x128 kernel (43 -> 39 us alone; both together -17 us in the step)
+        if (g_route_small && EPI == EPI_STD && ring_ok && !a.a_kmajor && a.b_kmajor && split == 1 && a.K >= 1536 && a.K <= 4096 &&
+            big_tiles >= 128 && big_tiles < 512) kern = KERN_TALLP;
         if (g_gemm_mode == 1) kern = KERN_REG;
         else if (g_gemm_mode == 5 && ring_ok && (EPI == EPI_STD || !any_km)) kern = KERN_WIDE;
         else if (g_gemm_mode == 6 && ring_ok && EPI == EPI_STD) kern = KERN_QUAD;
@@ -2014,6 +2022,7 @@ extern "C" int capdecdbg_occupy(int wgs, int lds_bytes, long microseconds, void*
 extern "C" void capdecdbg_gemm_stamps(void* device_buffer) { g_stamps = (unsigned long long*)device_buffer; }
 extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
 extern "C" void capdecdbg_gemm_a_panel(long rows) { g_dbg_a_panel = rows; }
+extern "C" void capdecdbg_gemm_route_small(int on) { g_route_small = on; }
 extern "C" void capdecdbg_gemm_extra_lds(int bytes) { g_extra_lds = bytes > 0 ? bytes : 0; }
 
 // ==================================================================== C ABI
