@@ -2224,9 +2224,10 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
         if (head_fwd_supported(ha)) return head_fwd_launch(ha, g_gemm_mode == 11 ? 0 : 1, (hipStream_t)stream);
     }
     // ... and those that add a dropped-out product to an f32 residual stream (the out_proj and linear2 forwards); shallow ones
-    // of 192 to 511 tall tiles (out_proj on the 8192 scored rows of a batch of 256: 31.3 -> 24.4 us) take the 256x128 geometry
+    // of 192 to 511 tall tiles (out_proj and linear2 on the 8192 scored rows of a batch of 256: 31.3 -> 24.4 and 48.9 -> 41.2 us
+    // alone, -4.5 and -6.5 us in the step) take the 256x128 geometry
     const long tall_tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-    const bool small_residual = tall_tiles >= 192 && tall_tiles < 512 && a.K <= 1024;
+    const bool small_residual = tall_tiles >= 192 && tall_tiles < 512 && a.K <= 2048;
     if (d->in_dtype == CAPDEC_BF16 && a.out_dtype == CAPDEC_F32 && !a.a_kmajor && !a.b_kmajor && a.residual && !a.accumulate &&
         a.gate_mode == CAPDEC_GATE_NONE && !a.aux_out && !a.colsum && !a.kv_cache && a.act == CAPDEC_ACT_NONE && a.col_scale_n == 0 &&
         (g_gemm_mode == 10 || g_gemm_mode == 11 || (g_gemm_mode == 0 && ((long)a.M * a.N >= (1L << 25) || small_residual)))) {
