@@ -322,7 +322,10 @@ int capdec_logits_ce_fwd_ref(const void* h, const void* W, const float* bias, in
  * (patched IN PLACE here).  Writes rowscale[m] = g[m] ([M] f32) and h_scaled[m,:] = g[m] * h[m,:] (bf16 [M, ld_hs]):
  *   d head.weight = probs'^T h_scaled,  d h = diag(rowscale) (probs' W)  (capdec_gemm_desc.row_scale),
  *   d head.bias = capdec_colsum_weighted(probs', rowscale), or, with rowscale_bf16 (optional [M] bf16 copy of g) as
- *   capdec_gemm_desc.kvec of the weight-gradient product, one more column of that product. */
+ *   capdec_gemm_desc.kvec of the weight-gradient product, one more column of that product.
+ * probs_panel_rows: 0 when probs is the matrix [M, ld_probs]; the R given to capdec_logits_ce_fwd_ref as
+ * capdec_kpanels.probs_rows when it is the column-panel image [ld_probs / 32][R][32] (capdec_colsum_weighted reads the
+ * matrix form only: with an image the bias gradient is the products' kvec column). */
 int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
                                      const void* h, long ldh, int d,
                                      const int64_t* labels, int B, int L,
