@@ -267,7 +267,8 @@ class CaptionTrainer:
     -- the vocabulary slabs first -- and overlapped with the rest of the backward."""
 
     def __init__(self, model: TransformerDecoder, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None,
-                 process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
+                 process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, grad_compress: Optional[str] = None,
+                 record_bucket_timing: bool = False):
         self.model = model
         self.lr = config.learning_rate if lr is None else lr
         self.weight_decay = config.weight_decay if weight_decay is None else weight_decay
@@ -285,7 +286,9 @@ class CaptionTrainer:
         self.grads = {key: self.store.grad(key) for key, _, _ in self.store.layout}
         self.step_count = 0
         from .dp import GradReducer
-        self.reducer = GradReducer(self.store, process_group, bucket_bytes=bucket_bytes, overlap=overlap)
+        # grad_compress="bf16": the ranks exchange bfloat16 gradients (half the bytes on the links); moments and update stay f32
+        self.reducer = GradReducer(self.store, process_group, bucket_bytes=bucket_bytes, overlap=overlap, compress=grad_compress,
+                                   record_timing=record_bucket_timing)
         if self.reducer.enabled and self.reducer.rank > 0:
             # every rank draws its own dropout masks: with one shared seed the shards of a global batch would all be
             # thinned by the same pattern (the engine is built lazily from the options, so this precedes its first use)

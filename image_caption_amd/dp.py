@@ -13,6 +13,11 @@ all-reduce (RCCL over xGMI when the backend is "nccl") is issued asynchronously
 as soon as the slice is complete; the remaining backward kernels keep running on
 the compute stream.  ``finish`` makes the compute stream wait for all buckets
 before the optimiser kernel reads the gradients.
+
+``compress="bf16"`` halves the bytes on the links: a bucket is rounded to bfloat16
+into a staging buffer on the compute stream, the staging slice is what the ranks
+sum, and after the bucket's wait it is widened back into the f32 gradient buffer,
+which the optimiser reads as before (f32 moments, f32 update).
 """
 from __future__ import annotations
 
@@ -31,9 +36,19 @@ HEAD_W, HEAD_B = "output_projection.weight", "output_projection.bias"
 
 
 class GradReducer:
-    def __init__(self, store, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
+    def __init__(self, store, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True,
+                 compress: Optional[str] = None, record_timing: bool = False):
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
         self.store = store
         self.group = process_group
+        self.compress = compress
+        self._stage: Optional[torch.Tensor] = None    # bf16 image of the gradient buffer (compress="bf16"), made on first use
+        # record_timing: an event on the compute stream at every bucket's issue and at the start of drain()/finish()
+        # (= the end of the backward), so that a run can report how long before the end each bucket left
+        self.record_timing = record_timing
+        self.issue_events: List = []
+        self.backward_end_event = None
         # CAPDEC_DP_SINGLE_RANK=1 keeps the exchange on with one rank (every all-reduce is then an identity):
         # a rehearsal of the RCCL call pattern on a one-GPU machine
         single_ok = os.environ.get("CAPDEC_DP_SINGLE_RANK", "0") == "1"
@@ -66,14 +81,55 @@ class GradReducer:
         self.sent_end = 0
         self.works = []
         self.bucket_log = []
+        self.issue_events = []
+        self.backward_end_event = None
+
+    @staticmethod
+    def _convert(src: torch.Tensor, dst: torch.Tensor):
+        if src.is_cuda:
+            from . import ops
+            ops.cast(src, dst)
+        else:                      # host tensors (the gloo tests of the bucket logic)
+            dst.copy_(src)
+
+    def _mark(self):
+        if self.record_timing and self.store.g.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return None
 
     def _launch(self, end: int):
         if end <= self.sent_end:
             return
-        sl = self.store.g[self.sent_end:end]
-        self.bucket_log.append((self.sent_end, end))
+        a = self.sent_end
+        sl = self.store.g[a:end]
+        if self.compress == "bf16":
+            if self._stage is None or self._stage.device != self.store.g.device:
+                self._stage = torch.empty(self.store.numel, dtype=torch.bfloat16, device=self.store.g.device)
+            # on the compute stream, after the kernels that produced the slice; the collective is ordered after it
+            self._convert(sl, self._stage[a:end])
+            sl = self._stage[a:end]
+        self.bucket_log.append((a, end))
+        self.issue_events.append(self._mark())
         self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.sent_end = end
+
+    def _complete(self, work, a: int, b: int):
+        work.wait()
+        if self.compress == "bf16":
+            self._convert(self._stage[a:b], self.store.g[a:b])
+
+    def payload_bytes(self) -> int:
+        """Bytes one rank hands to the collective per step."""
+        return self.store.numel * (2 if self.compress == "bf16" else 4)
+
+    def issue_lead_ms(self):
+        """[(start, end, ms between the bucket's issue and the end of the backward)] of the last step (record_timing)."""
+        if self.backward_end_event is None:
+            return []
+        torch.cuda.synchronize()
+        return [(a, b, ev.elapsed_time(self.backward_end_event)) for (a, b), ev in zip(self.bucket_log, self.issue_events) if ev is not None]
 
     def on_grad_ready(self, key, v0: int, nv: int):
         """Called by the engine when a piece of the gradient is final:
@@ -102,9 +158,10 @@ class GradReducer:
     def finish(self):
         if not self.enabled:
             return
+        self.backward_end_event = self._mark()
         self._launch_rest()
-        for w in self.works:
-            w.wait()
+        for w, (a, b) in zip(self.works, self.bucket_log):
+            self._complete(w, a, b)
         self.works = []
 
     def drain(self, apply):
@@ -114,9 +171,10 @@ class GradReducer:
         if not self.enabled:
             apply(0, self.store.numel)
             return
+        self.backward_end_event = self._mark()
         self._launch_rest()
         for w, (a, b) in zip(self.works, self.bucket_log):
-            w.wait()
+            self._complete(w, a, b)
             apply(a, b)
         self.works = []
 

@@ -7,10 +7,11 @@
      'caption_labels':    [B, L] int64}
 
 with S = P + 1 + L (img_text_concat.py:98-99) and the three shape checks of
-img_text_concat.py:126-128.  What differs is the INPUT: the reference computes the
-embeddings from PIL images and strings with frozen ViT / GPT-2 encoders
-(img_text_concat.py:32-65), which are outside this package; here the batch
-carries the embeddings themselves.
+img_text_concat.py:126-128.  The reference computes the embeddings from PIL images
+and strings with frozen ViT / GPT-2 encoders built at import time
+(img_text_concat.py:8-65); those are outside this package, so a batch either
+carries the embeddings themselves or is the reference's {'image', 'caption'} dict
+together with injected encoder callables (``Encoders``).
 """
 from __future__ import annotations
 
@@ -36,9 +37,65 @@ def join_prefix(image_embeddings: torch.Tensor, sos_embedding: torch.Tensor, cap
     return out.view(S, B, d)
 
 
-def process_batch(batch):
-    """batch = {'image_embeddings': [B,P,d], 'sos_embedding': [B,1,d],
-    'caption_embeddings': [B,L,d], 'caption_input_ids': [B,L], 'caption_labels': [B,L]}."""
+class Encoders:
+    """The frozen models the reference builds at import time (img_text_concat.py:8-27), as injectable callables:
+    they need downloaded assets, so this package constructs none of them.
+
+      get_patch_embeddings(images)  -> [B,P,d] float   (img_text_concat.py:32-50: ViT patches without the CLS row)
+      get_token_embeddings(strings) -> [B,L,d] float   (img_text_concat.py:52-65: text-model hidden states, padded /
+                                                        truncated to max_caption_length; the callable adds its own
+                                                        "<sos> ... <eos>" wrapping exactly as the reference's does)
+      tokenizer(strings, padding=, max_length=, truncation=, return_tensors=) -> {'input_ids': [B,L] int64}
+      sos_embedding(batch_size)     -> [B,1,d] float   (img_text_concat.py:102-104: hidden state of a lone "<sos>")
+    """
+
+    def __init__(self, get_patch_embeddings, get_token_embeddings, tokenizer, sos_embedding):
+        self.get_patch_embeddings = get_patch_embeddings
+        self.get_token_embeddings = get_token_embeddings
+        self.tokenizer = tokenizer
+        self.sos_embedding = sos_embedding
+
+
+# what process_batch() uses for the reference's {'image', 'caption'} batches when no `encoders` argument is given
+default_encoders = None
+
+
+def set_encoders(encoders):
+    """Installs the module-wide encoders (the counterpart of the reference's module-level vit_model / text_model /
+    tokenizer objects), so that ``process_batch(batch)`` can be called with the reference's one-argument form."""
+    global default_encoders
+    default_encoders = encoders
+
+
+def _embed_reference_batch(batch, enc):
+    """The reference's own batch form {'image': [PIL images], 'caption': [str]} -> the five tensors of the embeddings
+    form, through injected encoders (img_text_concat.py:69-104, same strings in the same order)."""
+    captions = list(batch["caption"])
+    with_sos = ["<sos> " + c for c in captions]
+    tok = dict(padding="max_length", max_length=max_caption_length, truncation=True, return_tensors="pt")
+    return {
+        "image_embeddings": enc.get_patch_embeddings(batch["image"]),
+        "caption_embeddings": enc.get_token_embeddings(with_sos),
+        "sos_embedding": enc.sos_embedding(len(captions)),
+        "caption_input_ids": enc.tokenizer(with_sos, **tok)["input_ids"],
+        "caption_labels": enc.tokenizer([c + " <eos>" for c in captions], **tok)["input_ids"],
+    }
+
+
+def process_batch(batch, *, encoders=None):
+    """Two batch forms, one output contract (img_text_concat.py:130-134):
+
+      * the reference's own: {'image': [PIL images], 'caption': [str]} (img_text_concat.py:67-70) -- needs encoders
+        (the ``encoders`` argument or ``set_encoders``), since the frozen ViT / GPT-2 models are not part of this package;
+      * embeddings already computed: {'image_embeddings': [B,P,d], 'sos_embedding': [B,1,d],
+        'caption_embeddings': [B,L,d], 'caption_input_ids': [B,L], 'caption_labels': [B,L]}.
+    """
+    if "image_embeddings" not in batch:
+        enc = encoders if encoders is not None else default_encoders
+        if enc is None:
+            raise ValueError("a {'image', 'caption'} batch needs encoders: pass process_batch(batch, encoders=Encoders(...)) "
+                             "or call set_encoders() once (the frozen ViT / GPT-2 models are not constructed by this package)")
+        batch = _embed_reference_batch(batch, enc)
     image_embeddings = batch["image_embeddings"]
     sos_embedding = batch["sos_embedding"]
     caption_embeddings = batch["caption_embeddings"]

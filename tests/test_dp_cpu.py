@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from helpers import ROOT
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, compress=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -21,10 +21,13 @@ def _worker(rank, world, port, overlap, q):
         from image_caption_amd.engine import HEAD_B, HEAD_W, ModelGeometry, ParamStore
         geo = ModelGeometry(64, 2, 128, 503, n_blocks=2)
         st = ParamStore(geo, "cpu", torch.float32, with_optimizer_state=False)
-        red = GradReducer(st, None, bucket_bytes=40_000, overlap=overlap)
+        red = GradReducer(st, None, bucket_bytes=40_000, overlap=overlap, compress=compress)
+        # (bf16 exchange: values and sums below 256 are exact in bfloat16, so the same equality holds)
+        big = 1000 if compress is None else 64
+        assert red.payload_bytes() == st.numel * (4 if compress is None else 2)
         assert red.enabled and red.world_size == world
         for step in range(2):
-            st.g.copy_(torch.arange(st.numel, dtype=torch.float32) % 97 + (rank + 1) * 1000 + step)
+            st.g.copy_(torch.arange(st.numel, dtype=torch.float32) % 61 + (rank + 1) * big + step)
             red.begin()
             V, slab = 503, 128
             for v0 in range(0, V, slab):                      # the order loss_and_grads announces gradients in
@@ -38,7 +41,7 @@ def _worker(rank, world, port, overlap, q):
                 seen = []
                 red.drain(lambda a, b: seen.append((a, b)))
                 assert seen == red.bucket_log and seen[0][0] == 0 and seen[-1][1] == st.numel
-            want = (torch.arange(st.numel, dtype=torch.float32) % 97) * world + sum((r + 1) * 1000 + step for r in range(world))
+            want = (torch.arange(st.numel, dtype=torch.float32) % 61) * world + sum((r + 1) * big + step for r in range(world))
             assert torch.equal(st.g, want), "all-reduce result wrong"
             log = red.bucket_log
             assert log[0][0] == 0 and log[-1][1] == st.numel
@@ -54,12 +57,12 @@ def _worker(rank, world, port, overlap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_bucketed_allreduce_two_ranks(overlap):
+@pytest.mark.parametrize("overlap,compress", [(True, None), (False, None), (True, "bf16")])
+def test_bucketed_allreduce_two_ranks(overlap, compress):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400) + (1 if overlap else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 400) + (1 if overlap else 0) + (2 if compress else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, compress)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

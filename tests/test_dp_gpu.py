@@ -17,7 +17,7 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="gloo"):
+def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="gloo", compress=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -39,7 +39,7 @@ def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="glo
             m.load_state_dict(sd)
             m = m.to("cuda")
             m.train()
-            tr = CaptionTrainer(m, lr=1e-3, weight_decay=0.01, bucket_bytes=64 << 10)
+            tr = CaptionTrainer(m, lr=1e-3, weight_decay=0.01, bucket_bytes=64 << 10, grad_compress=compress if distributed else None)
             if not distributed:
                 tr.reducer.enabled = False
                 tr.reducer.world_size = 1
@@ -75,6 +75,11 @@ def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="glo
         elif rank == 0:
             want, ref_losses, _, _ = train(0, sh.B, False)
             tol = 2e-6 if dtype == torch.float32 else 2e-3
+            if compress == "bf16":
+                # gradients rounded to bfloat16 (relative 2^-9) before the sum: Adam's first two updates are
+                # lr * g / (|g| + eps)-like, so a parameter moves by at most 2 * lr = 2e-3 in all and the rounding
+                # changes that by at most 2 * lr * 2^-8 = 8e-6; the bound is on the parameter DIFFERENCE against the f32 exchange
+                tol = 5e-5
             for k in want:
                 err = (got[k] - want[k]).abs().max().item()
                 if err > tol * (want[k].abs().max().item() + 1.0):
@@ -99,6 +104,21 @@ def test_two_rank_training_matches_single_process(dtype_name, batch, dropout):
     q = ctx.Queue()
     port = 29950 + (os.getpid() % 40) + (0 if dtype_name == "float32" else 1) + 2 * batch + (50 if dropout else 0)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, q, batch, dropout)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_two_rank_training_with_bf16_gradient_exchange():
+    """GradReducer(compress="bf16"): parameters after two steps stay within the stated bound of single-process
+    training (whose gradients never leave f32), and several buckets were exchanged."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29810 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "float32", q, 6, 0.0, "gloo", "bf16")) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

@@ -1,6 +1,7 @@
 """Parity at the sizes the benchmark runs (the kernels the dispatcher picks there are not the ones small shapes reach):
   * the vocabulary-sized products at 8192 scored rows (batch 256) against torch f32 products of the same operands;
-  * one training step at batch 256, config.py defaults: bf16 and f32 modes against the CPU oracle and each other;
+  * one training step at batch 256, config.py defaults: loss and all gradients of the bf16 and f32 modes against the CPU oracle;
+  * one training step at batch 2048 (the data-parallel configuration's global batch on one GPU) against the chunked CPU oracle;
   * the scaled configuration (12 blocks, 257 patches, prefix-causal mask) at d=768 against the CPU oracle;
   * KV-cached greedy decoding of 4096 images, whose first 8 are the reference-composed fixture's.
 Tolerances as in test_parity_gpu.py (f32: loss 1e-5, grads 1e-4 of the tensor's max; bf16: loss 1e-2, cosine 0.999,
@@ -87,17 +88,83 @@ def test_head_products_at_batch_256():
 
 
 # ---------------------------------------------------------------------------- configs[1]: one step at batch 256
+def _oracle_step(sh, sd, img, sos, cap, labels, relu_gate=None):
+    """decoder.py:169-189 on the CPU with the vocabulary projection on the scored rows only (the other 197 rows' logits
+    never reach the loss): loss, argmax hits and all 14 gradients."""
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    blocks, head = ref_cpu.split_params(leaf)
+    keep = [{"relu_gate": relu_gate}] if relu_gate is not None else None
+    hid = ref_cpu.decoder_hidden(ref_cpu.concat_prefix(img, sos, cap), blocks, sh.nhead, keep=keep)
+    tail = hid[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]
+    loss, correct, _ = ref_cpu.caption_loss(tail, labels, sh.L)
+    loss.backward()
+    return loss.item(), correct, {k: leaf[k].grad for k in ref_cpu.PARAM_KEYS}
+
+
 def test_default_config_batch_256_step():
+    """Loss, hit count and ALL 14 gradients of one batch-256 step against the CPU oracle's backward: the f32 mode
+    element-wise (1e-4 of each tensor's maximum), the bf16 mode by cosine."""
     sh = Shape(B=256)
     sd = helpers.make_state_dict(sh, seed=303)
     img, sos, cap, labels = helpers.make_embeddings(sh, seed=2560)
-    # oracle: forward only, vocabulary projection on the 32 scored rows (1.6 GB of f32 logits instead of 11.8 GB)
+    dev_in = (img.to(DEV), sos.to(DEV), cap.to(DEV))
+    runs = {}
+    gate = None
+    for dtype in (F32, BF16):
+        m = make_model(sh, sd, dtype)
+        m.train()
+        loss, correct = m.caption_loss(dev_in, labels.to(DEV))
+        loss.backward()
+        assert m.engine.last_from_probs and m.engine.last_slab >= sh.vocab      # the whole-vocabulary kept-numerator path ran
+        runs[dtype] = (loss.item(), int(correct.item()), {k: p.grad.cpu() for k, p in m.named_parameters()})
+        if dtype == F32:
+            # 16.8 million ReLU gates on the scored rows: the few pre-activations within f32 summation-order noise of
+            # zero may land on the other side in the oracle, and one flipped gate moves a term of the gradients read
+            # through it by 1e-3 of a tensor's maximum.  The oracle takes the f32 run's on/off pattern (the other rows'
+            # MLP does not reach the loss: any pattern serves there)
+            a1 = m.engine.saved[0]["a1"]
+            gate = torch.ones(sh.S * sh.B, sh.ff)
+            gate[sh.S * sh.B - a1.shape[0]:] = (a1 != 0).float().cpu()
+            gate = gate.reshape(sh.S, sh.B, sh.ff)
+        del m
+    ref_loss, ref_correct, ref_grads = _oracle_step(sh, sd, img, sos, cap, labels, relu_gate=gate)
+    for dtype in (F32, BF16):
+        loss, correct, grads = runs[dtype]
+        assert abs(loss - ref_loss) <= (1e-5 if dtype == F32 else 1e-2) * ref_loss, (dtype, loss, ref_loss)
+        # hits among 8192 rows with random labels: a handful at most; bf16 may move one or two near-ties
+        assert abs(correct - ref_correct) <= (0 if dtype == F32 else 3)
+        for k in ref_cpu.PARAM_KEYS:
+            if dtype == F32:
+                err = (grads[k] - ref_grads[k]).abs().max().item()
+                assert err <= 1e-4 * ref_grads[k].abs().max().item() + 1e-10, (k, err)
+            else:
+                c = cos(grads[k], ref_grads[k])
+                assert c >= grad_bar(k), (k, c)
+
+
+# ---------------------------------------------------------------------------- configs[2] at N = 1: one step at batch 2048
+def test_global_batch_2048_step_on_one_gpu():
+    """The data-parallel configuration's whole global batch on one GPU (decoder.py:157-190 at batch 2048): 65 536 scored
+    rows, so the weight-gradient product with its bias column is cut into 8192-row slabs and d(logits) is a 6.6 GB
+    column-panel image.  Oracle: the CPU forward in chunks of 128 samples (samples are independent and the loss is a
+    mean: the chunks' loss sums add up; no 13 GB logits tensor on the host).  Loss: f32 1e-5, bf16 1e-2; hit count: f32
+    exact; gradients: bf16 against the f32 mode by cosine (the f32 mode's gradients meet the oracle's at batch 256 above
+    and at the golden shapes)."""
+    sh = Shape(B=2048)
+    sd = helpers.make_state_dict(sh, seed=303)
+    img, sos, cap, labels = helpers.make_embeddings(sh, seed=20480)
+    blocks, head = ref_cpu.split_params(sd)
+    ref_sum, ref_correct, chunk = 0.0, 0, 128
     with torch.no_grad():
-        blocks, head = ref_cpu.split_params(sd)
-        hid = ref_cpu.decoder_hidden(ref_cpu.concat_prefix(img, sos, cap), blocks, sh.nhead)
-        tail = hid[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]
-        ref_loss, ref_correct, _ = ref_cpu.caption_loss(tail, labels, sh.L)
-        del hid, tail
+        for lo in range(0, sh.B, chunk):
+            hi = lo + chunk
+            hid = ref_cpu.decoder_hidden(ref_cpu.concat_prefix(img[lo:hi], sos[lo:hi], cap[lo:hi]), blocks, sh.nhead)
+            tail = hid[-sh.L:] @ head["output_projection.weight"].t() + head["output_projection.bias"]
+            lo_loss, co, _ = ref_cpu.caption_loss(tail, labels[lo:hi], sh.L)
+            ref_sum += lo_loss.double().item() * (hi - lo) * sh.L
+            ref_correct += co
+            del hid, tail
+    ref_loss = ref_sum / (sh.B * sh.L)
     dev_in = (img.to(DEV), sos.to(DEV), cap.to(DEV))
     grads = {}
     for dtype in (F32, BF16):
@@ -105,11 +172,16 @@ def test_default_config_batch_256_step():
         m.train()
         loss, correct = m.caption_loss(dev_in, labels.to(DEV))
         loss.backward()
-        assert abs(loss.item() - ref_loss.item()) <= (1e-5 if dtype == F32 else 1e-2) * ref_loss.item(), (dtype, loss.item(), ref_loss.item())
-        # hits among 8192 rows with random labels: a handful at most; bf16 may move one or two near-ties
-        assert abs(int(correct.item()) - ref_correct) <= (0 if dtype == F32 else 3)
-        assert m.engine.last_from_probs and m.engine.last_slab >= sh.vocab      # the whole-vocabulary kept-numerator path ran
+        assert abs(loss.item() - ref_loss) <= (1e-5 if dtype == F32 else 1e-2) * ref_loss, (dtype, loss.item(), ref_loss)
+        assert abs(int(correct.item()) - ref_correct) <= (0 if dtype == F32 else 8), (dtype, int(correct.item()), ref_correct)
+        eng = m.engine
+        assert eng.last_from_probs and eng.last_slab >= sh.vocab
+        if dtype == BF16:
+            # numerators against one reference per row, kept as a column-panel image, bias gradient as a column of the
+            # row-cut weight-gradient product
+            assert eng.last_by_row and eng.last_dl_panels and eng.opt.ce_bias_in_wgrad
         grads[dtype] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        assert all(bool(torch.isfinite(g).all()) for g in grads[dtype].values())
         del m
     for k in ref_cpu.PARAM_KEYS:
         c = cos(grads[BF16][k], grads[F32][k])

@@ -148,3 +148,12 @@ def test_greedy(name, sh, seeds, gain):
                                              return_margins=True)
     assert np.array_equal(ids.numpy(), g[f"greedy_{name}_ids"])
     np.testing.assert_allclose(margins.numpy(), g[f"greedy_{name}_margins"], atol=5e-4)
+
+
+def test_oracle_gelu_is_torch_gelu():
+    """The one arithmetic of the oracle that no reference vector pins (the reference hard-codes ReLU, decoder.py:60):
+    its erf-form GELU is torch.nn.functional.gelu's."""
+    import torch
+    from oracle import ref_cpu
+    x = torch.linspace(-8.0, 8.0, 4001)
+    assert torch.allclose(ref_cpu._activation(x, "gelu"), torch.nn.functional.gelu(x), rtol=0, atol=2e-6)      # a few f32 ulp at |x| = 8 (measured 9.5e-7)

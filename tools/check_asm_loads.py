@@ -128,7 +128,8 @@ def main():
                 cur = None
     total = 0
     for name, lines in kernels:
-        if want not in name or not any("ds_read_b64_tr_b16" in l for _, l in lines):
+        has_asm_read = any("ds_read_b64_tr_b16" in l or (no in ASM_LINES and l.strip().startswith("ds_read")) for no, l in lines)
+        if want not in name or not has_asm_read:
             continue
         bad = check(lines, name)
         total += len(bad)
