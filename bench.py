@@ -72,6 +72,9 @@ def parse():
                     help="the kept softmax numerators / d(logits) stay a row-major matrix (A/B of the column-panel image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="no event brackets inside the timed steps (A/B of their cost)")
+    ap.add_argument("--stage-steps", type=int, default=5,
+                    help="extra untimed steps with an event bracket around every stage, after the timed ones (0: none, so that a "
+                         "kernel trace of the run ends with the timed steps)")
     ap.add_argument("--no-greedy", action="store_true")
     ap.add_argument("--no-scaled", action="store_true", help="skip the 12-block / 257-patch leg")
     ap.add_argument("--no-global-2048", action="store_true", help="skip the fixed-global-batch-2048 leg")
@@ -186,7 +189,7 @@ def pmc_traffic(span, args, B, whole_vocab):
     """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE cannot be collected inside this process); None unless this run has the configuration the
     counters were collected on."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             doc = json.load(open(path))
@@ -374,7 +377,8 @@ def main():
     # two 20-35 ms stalls (tools/warmup_probe.py shows them: clock / power-state changes or runtime housekeeping, at a
     # different step from run to run), which a short warm-up leaves inside the timed steps.  A fixed number of steps, so
     # that every rank issues the same collectives.
-    elapsed, out, spans = timed(model, trainer, B, args.patches, args.steps, args.warmup, args.spinup_steps, spans_wanted=not args.no_spans)
+    elapsed, out, spans = timed(model, trainer, B, args.patches, args.steps, args.warmup, args.spinup_steps, spans_wanted=not args.no_spans,
+                                stage_steps=args.stage_steps)
     loss = out[0].item() / out[2]
     slab = model.engine.last_slab
 
@@ -448,10 +452,12 @@ def scaled_bench(build, timed, args):
     value = B * 10 / elapsed
     # where the step goes: five more steps with event brackets around the stages (outside the timed region: a
     # bracket is two event records, and this configuration has some 300 of them per step)
-    _, _, spans = timed(model, trainer, B, P, 5, 0, 0)
-    stage_ms = {k: round(ms * c / 5, 3) for k, (c, ms) in spans.items()}
+    stage_ms = {}
+    if args.stage_steps > 0:
+        _, _, spans = timed(model, trainer, B, P, 5, 0, 0)
+        stage_ms = {k: round(ms * c / 5, 3) for k, (c, ms) in spans.items()}
     tf = value * SCALED_TRAIN_FLOPS_PER_SAMPLE / 1e12
-    top = max(stage_ms, key=stage_ms.get)
+    top = max(stage_ms, key=stage_ms.get) if stage_ms else None
     return {"metric": "train samples/sec", "value": round(value, 1), "unit": "samples/s", "ms_per_step": round(elapsed / 10 * 1e3, 3),
             "steps": 10, "dtype": args.dtype,
             "config": {"workload": f"single training step at batch {B}, {nb} blocks, P={P} (S={P + 33}), d=768, H=8, ff=2048, "

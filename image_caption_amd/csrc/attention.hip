@@ -1046,7 +1046,8 @@ bool strides_ok8(long a, long b, long c) { return (a % 8) == 0 && (b % 8) == 0 &
 
 template <typename K>
 void set_lds(K kernel, int bytes) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)bytes;                                      // the ceiling is raised once to the CU's 160 KiB, whatever this launch asks for
+    ensure_dynamic_lds((const void*)kernel, 160 * 1024);
 }
 
 #define HD_DISPATCH(HDV, ...)                                      \

@@ -39,6 +39,32 @@ void capdec_set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---------------------------------------------------------------- dynamic LDS above 64 KiB
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: it is set once per (kernel, device),
+// whichever host thread launches first there (lock-free table; a full table or an unknown device sets it every time).
+inline void ensure_dynamic_lds(const void* fn, int bytes) {
+    struct Slot { const void* fn; unsigned long long devs; };
+    static Slot table[512];
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        const size_t h = (size_t)(((uintptr_t)fn >> 4) * 2654435761u);
+        for (int probe = 0; probe < 512; ++probe) {
+            Slot& s = table[(h + probe) & 511];
+            const void* cur = __atomic_load_n(&s.fn, __ATOMIC_ACQUIRE);
+            if (!cur) {
+                const void* expected = nullptr;
+                cur = __atomic_compare_exchange_n(&s.fn, &expected, fn, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? fn : expected;
+            }
+            if (cur != fn) continue;
+            if (__atomic_load_n(&s.devs, __ATOMIC_ACQUIRE) & (1ull << dev)) return;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            __atomic_fetch_or(&s.devs, 1ull << dev, __ATOMIC_RELEASE);
+            return;
+        }
+    }
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 // ---------------------------------------------------------------- dtype access
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -1450,11 +1450,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
     do {                                                                                               \
         using G = DmaGeo<WM, WN, TI, NST>;                                                             \
         auto kfn = gemm_bf16_dma_kernel<AT, BT, EPI, WM, WN, TI, NST>;                                 \
-        static bool attr_set = false;                                                                  \
-        if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                           \
-        }                                                                                              \
+        ensure_dynamic_lds((const void*)kfn, 160 * 1024); \
         const int lds_bytes = G::LDS + g_extra_lds <= 160 * 1024 ? G::LDS + g_extra_lds : G::LDS;      \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(64 * G::NW), lds_bytes, st, a);    \
     } while (0)
@@ -1462,34 +1458,21 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
     do {                                                                                               \
         if (kern == KERN_RING128) CAPDEC_RING_LAUNCH(AT, BT, 2, 2, 4, 4, nwg);                            \
         else {                                                                                         \
-            static bool attr_set = false;                                                              \
-            if (!attr_set) {                                                                           \
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AT, BT, EPI>,                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);      \
-                attr_set = true;                                                                       \
-            }                                                                                          \
+            ensure_dynamic_lds((const void*)gemm_bf16_kernel<AT, BT, EPI>, LDS_BYTES); \
             hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, EPI>), grid, block, LDS_BYTES, st, a);        \
         }                                                                                              \
     } while (0)
 #define CAPDEC_PIPE_LAUNCH(AT, BT, E, TJ, NWG)                                                         \
     do {                                                                                               \
         auto kfn = gemm_bf16_pipe_kernel<AT, BT, E, TJ>;                                               \
-        static bool attr_set = false;                                                                  \
-        if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                           \
-        }                                                                                              \
+        ensure_dynamic_lds((const void*)kfn, 160 * 1024); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(NWG), split), dim3(256), PipeGeo<TJ>::LDS, st, a);     \
     } while (0)
 #define CAPDEC_QUAD_LAUNCH(AT, BT) CAPDEC_PIPE_LAUNCH(AT, BT, EPI_STD, 8, wide_tiles)
 #define CAPDEC_QUAD_KVEC_LAUNCH(MODE)                                                                  \
     do {                                                                                               \
         auto kfn = gemm_bf16_pipe_kernel<true, true, EPI_STD, 8, MODE>;                                \
-        static bool attr_set = false;                                                                  \
-        if (!attr_set) {                                                                               \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                           \
-        }                                                                                              \
+        ensure_dynamic_lds((const void*)kfn, 160 * 1024); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(wide_tiles), split), dim3(256), PipeGeo<8>::LDS + (MODE == 1 ? KVEC_BYTES : 0), st, a); \
         t_kvec_done = true;                                                                            \
     } while (0)
@@ -1547,11 +1530,7 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 #undef CAPDEC_QUAD_KVEC_LAUNCH
 #undef CAPDEC_PIPE_LAUNCH
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<float, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            attr_set = true;
-        }
+        ensure_dynamic_lds((const void*)gemm_f32_kernel<float, EPI>, LDS_BYTES);
         hipLaunchKernelGGL((gemm_f32_kernel<float, EPI>), grid, block, LDS_BYTES, st, a);
     }
     CAPDEC_LAUNCH_CHECK();

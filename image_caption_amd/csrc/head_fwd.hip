@@ -14,7 +14,11 @@
 //     reduction.  No LDS staging, so the ring keeps filling underneath, and nothing waits for LDS round trips;
 //   * maximum and argmax in one pass: the 6-bit column index replaces the low mantissa bits of each logit and an
 //     ordinary float max carries it along.  The reference r is that packed value (within 2^-17 relative of the true
-//     maximum), which is all a softmax reference needs: numerators, sums and the final log-sum-exp stay exact;
+//     maximum), which is all a softmax reference needs: numerators, sums and the final log-sum-exp stay exact.
+//     TIE RULE of the argmax: logits within 64 ulp (2^-17 relative) of each other are not told apart by value; among
+//     them the lowest column wins (exactly equal logits therefore resolve as torch.argmax does).  Mode 0 holds to
+//     that for either sign; mode 3 packs for positive values only -- its values are z - z_label, a row's maximum is
+//     never below the label's ~0, and a negative slot maximum cannot win the row;
 //   * the bias initialises the accumulators (first MFMA of a tile takes it as its C operand); a tile's slice of it
 //     travels through the LDS like the operands do (one more DMA piece per tile), because an ordinary register load
 //     next to in-flight LDS-DMA makes the compiler drain every outstanding memory operation before its first use;
@@ -348,7 +352,25 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const float f = __uint_as_float((__float_as_uint(v[t]) & 0xFFFFFFC0u) | c);
                     pm = t == 0 ? f : fmaxf(pm, f);
                 }
-                pm = quad_max(__uint_as_float(__float_as_uint(pm) | qbits));
+                bool neg_rule = false;
+                if constexpr (MODE == 0) {
+                    // A negative float grows more negative with its low bits, so under the packing above the HIGHEST
+                    // column would win among (nearly) equal negative values.  Where a row's slot maximum is negative
+                    // (every one of its 64 logits is: rare, so behind a wave-uniform branch) the lane's candidates are
+                    // packed again with the index as it is, and the lowest column wins as it does for positive values.
+                    neg_rule = quad_max(pm) < 0.f;
+                    if (__builtin_amdgcn_ballot_w64(neg_rule) != 0) {
+                        float pn = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const unsigned c = (unsigned)(((t >> 2) << 4) | (t & 3));
+                            const float f = __uint_as_float((__float_as_uint(v[t]) & 0xFFFFFFC0u) | c);
+                            pn = t == 0 ? f : fmaxf(pn, f);
+                        }
+                        if (neg_rule) pm = pn;
+                    }
+                }
+                pm = quad_max(__uint_as_float(__float_as_uint(pm) | (neg_rule ? (unsigned)q << 2 : qbits)));
                 // mode 3: the values are z - (row reference) already, and the numerators and their sum are taken against
                 // that reference, not the slot's maximum; else a slot wholly past N: numerators exp2(-inf) = 0
                 const float nref = MODE == 3 ? 0.f : (pm > -1.0e38f ? -pm * LOG2E : 0.f);
@@ -364,7 +386,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const unsigned off = (q == 0 && row_ok && slot_ok) ? (unsigned)(r16 * 8) : 0xFFFFFFFFu;
                     __builtin_amdgcn_raw_buffer_store_b64(rec, prs, off, 0, 0);
                 } else {
-                    const int arg = nw + 63 - (int)(__float_as_uint(pm) & 63u);
+                    const int low6 = (int)(__float_as_uint(pm) & 63u);
+                    const int arg = nw + (neg_rule ? low6 : 63 - low6);
                     const f32x4 rec = {pm, sum, -INFINITY, __int_as_float(arg)};
                     const __amdgpu_buffer_rsrc_t prs = rsrc_at((const char*)(p.part4 + ((long)slot * p.M + mb)), 0xFFFFFFF0L);
                     const unsigned off = (q == 0 && row_ok && slot_ok) ? (unsigned)(r16 * 16) : 0xFFFFFFFFu;
@@ -430,15 +453,7 @@ int launch_geo(const HeadFwdArgs& a_in, hipStream_t st) {
     long grid = 256L * G::WG_PER_CU;                      // every workgroup resident at once; a multiple of the 8 XCDs
     if (tiles < grid) grid = tiles;
     auto go = [&](auto kfn) {
-        // once per kernel (the variants share one function type, so a flag local to this lambda would be shared too)
-        static const void* seen[8];
-        static int nseen = 0;
-        bool known = false;
-        for (int i = 0; i < nseen; ++i) known |= seen[i] == (const void*)kfn;
-        if (!known) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (nseen < 8) seen[nseen++] = (const void*)kfn;
-        }
+        ensure_dynamic_lds((const void*)kfn, 160 * 1024);      // once per (kernel, device)
         const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS && (a.mode == 0 || a.mode == 3) && a.C;      // the training forward only
         if (timing) (void)hipEventRecord(g_timing.ev[2 * g_timing.n], st);
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * G::NW), G::LDS, st, a);

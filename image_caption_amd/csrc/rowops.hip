@@ -987,13 +987,23 @@ static __device__ __align__(256) unsigned char scratch[COLSUM_STATIC_BYTES];
 namespace {
 constexpr int MAX_DEVICES = 64;
 void* g_scratch_ptr[MAX_DEVICES];            // per device: device address of `scratch`, 0 until first use there
-// address of this device's copy of the array (resolved once per device, with that device current)
-int static_scratch(void** out) {
+// address of this device's copy of the array (resolved once per device, with that device current).  The kernels run on
+// the device that owns `stream`: it has to be the current one, or the address would be another GPU's copy.
+int static_scratch(void** out, hipStream_t stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
         capdec_set_error("colsum_static: cannot identify the current device (%s)", hipGetErrorString(e));
         return CAPDEC_ERR_INVALID;
+    }
+    if (stream) {
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e == hipSuccess && (int)sdev != dev) {
+            capdec_set_error("colsum_static: the stream belongs to device %d, the current device is %d (make the stream's device current)", (int)sdev, dev);
+            return CAPDEC_ERR_INVALID;
+        }
+        (void)hipGetLastError();       // a runtime that cannot tell (e != hipSuccess) is not an error of this call
     }
     void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
     if (!p) {
@@ -1018,7 +1028,7 @@ extern "C" int capdec_colsum_static(const void* x, int dtype, long M, int N, lon
         return CAPDEC_ERR_WORKSPACE;
     }
     void* ws = nullptr;
-    const int rc = static_scratch(&ws);
+    const int rc = static_scratch(&ws, (hipStream_t)stream);
     if (rc) return rc;
     // every partial the fold reads is written by the stripe pass of the same call: nothing has to start at zero
     return capdec_colsum(x, dtype, M, N, ldx, colsum, ws, COLSUM_STATIC_BYTES, stream);

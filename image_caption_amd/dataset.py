@@ -123,12 +123,20 @@ class BatchSource:
         """A pinned copy of the split when it fits comfortably in the host memory available now (pinning materialises
         the whole slice); otherwise the view itself -- a mapped file larger than memory streams through pageable copies."""
         nbytes = x.numel() * x.element_size()
+        available = None                       # None: no figure to go by -> try to pin and fall back on failure
         try:
             import psutil
             available = psutil.virtual_memory().available
         except Exception:
-            available = 0
-        if nbytes > host_fraction * available:
+            try:
+                with open("/proc/meminfo") as f:
+                    for line in f:
+                        if line.startswith("MemAvailable:"):
+                            available = int(line.split()[1]) * 1024
+                            break
+            except (OSError, ValueError, IndexError):
+                available = None
+        if available is not None and nbytes > host_fraction * available:
             return x
         try:
             return x.contiguous().pin_memory()

@@ -244,7 +244,13 @@ int capdec_attn_decode(const void* q, const void* kv_cache, void* o, int dtype,
  * probs (optional, [M, ld_probs] of `dtype`, ld_probs a multiple of 8 in [V, roundup128(V)]):
  * receives the softmax numerators exp(z - max of the column's 64-wide slot) (columns V..ld_probs-1
  * zero); together with the workspace's per-slot maxima they let capdec_logits_ce_bwd_from_probs
- * form d(logits) without a second product over the vocabulary. */
+ * form d(logits) without a second product over the vocabulary.
+ * Tie rule of argmax / correct (and of capdec_logits_argmax's ids): exactly equal logits resolve to the lowest column,
+ * as torch.argmax does.  In float32, and wherever a margin is asked for, nothing else is a tie.  The bf16 products of
+ * at least 2^24 outputs run a kernel that carries the column in the low 6 mantissa bits of each logit: logits within
+ * 64 ulp (2^-17 relative) of the row's maximum are then not told apart by value, and the lowest column among them
+ * wins.  capdec_logits_ce_fwd_ref compares z - z_label instead of z, so its resolution is 2^-17 of the distance to the
+ * label's logit; a row whose maximum IS the label's column within rounding counts as correct. */
 long capdec_logits_ce_workspace(long M, int V);
 
 /* k-panel images of the two operands of the vocabulary product (decoder.py:66: h [M,d] and output_projection.weight
@@ -333,7 +339,9 @@ int capdec_logits_ce_bwd_ref_prepare(void* probs, long ld_probs, long M, int V,
                                      void* h_scaled, long ld_hs, float* rowscale, void* rowscale_bf16,
                                      long probs_panel_rows, void* stream);
 /* Greedy step: argmax_n(h W^T + bias) per row without writing logits.
- * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above. */
+ * out_ids [M] int64; optional margin [M] f32 = top1 - top2. workspace as above.  Ties: see capdec_logits_ce_fwd; with
+ * margin != NULL the ids are exact argmaxes, without it two logits within 2^-17 relative of each other may resolve to
+ * the lower column although the higher one is larger by less than that. */
 int capdec_logits_argmax(const void* h, const void* W, const float* bias, int dtype,
                          long M, int V, int d, long ldh, long ldw,
                          int64_t* out_ids, float* margin, const capdec_kpanels* panels,
@@ -367,7 +375,10 @@ int capdec_colsum_weighted(const void* x, int dtype, long M, int N, long ldx, co
  * stripe partials go to a fixed CAPDEC_COLSUM_STATIC_BYTES array inside the library's code object (one copy per GPU,
  * held until the process ends); the call allocates nothing and returns CAPDEC_ERR_WORKSPACE when
  * capdec_colsum_workspace(M, N) exceeds that size.  Results are bit-identical to capdec_colsum.  All calls on one GPU
- * share the array: calls that overlap in time on the same GPU (different streams) race. */
+ * share the array: calls that overlap in time on the same GPU (different streams) race.
+ * The device that owns `stream` must be the current device (checked: CAPDEC_ERR_INVALID otherwise) -- the array's
+ * address is per device.  The FIRST call on a device resolves that address (hipGetSymbolAddress, which may load the
+ * code object): make it outside any stream capture; later calls only launch kernels and can be captured into a graph. */
 #define CAPDEC_COLSUM_STATIC_BYTES (4L << 20)
 int capdec_colsum_static(const void* x, int dtype, long M, int N, long ldx, float* colsum, void* stream);
 /* rows of a token-embedding table: out[i,:] = table[ids[i],:] (+ pos row if given); out f32 */

@@ -237,6 +237,36 @@ def test_persistent_logits_ce_forward(gemm_mode, mode, B_, L, V, d, with_bias):
     assert int(ids.min()) >= 0 and int(ids.max()) < V
 
 
+@pytest.mark.parametrize("mode", [8, 9])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_persistent_argmax_tie_rule(gemm_mode, mode, sign):
+    """The packed argmax of the persistent kernel: exactly equal logits resolve to the lowest column for maxima of either
+    sign (torch.argmax's rule) -- inside a lane, across the lanes of a row, across 64-column slots --, and two logits
+    closer than 64 ulp resolve to one of the two."""
+    M, V, d = 48, 300, 256
+    h = rnd(M, d, dtype=torch.bfloat16, seed=81)
+    w = rnd(V, d, dtype=torch.bfloat16, scale=0.5 / math.sqrt(d), seed=82)
+    pairs = [(5, 6), (5, 37), (17, 201), (70, 127), (130, 299), (0, 63)]
+    ws = torch.empty(ops.logits_ce_workspace(M, V), dtype=torch.uint8, device=DEV)
+    for ulps in (0, 20):
+        for c1, c2 in pairs:
+            w2 = w.clone()
+            w2[c2] = w2[c1]                                   # same operands, same order of summation: equal bit for bit
+            # all other logits far below the pair; the pair's level positive or negative
+            b = torch.full((V,), -100.0 if sign > 0 else -300.0, device=DEV)
+            b[c1] = b[c2] = 50.0 * sign
+            if ulps:
+                b[c1] = torch.nextafter(b[c1], torch.tensor(-1e9, device=DEV))   # the LOWER column is smaller by a few ulp of the logit
+            ids = torch.full((M,), -1, dtype=torch.int64, device=DEV)
+            gemm_mode(mode)
+            ops.logits_argmax(h, w2, b, ids, None, ws)
+            gemm_mode(0)
+            if ulps == 0:
+                assert bool((ids == c1).all()), (sign, c1, c2, ids[:8].tolist())
+            else:
+                assert bool(((ids == c1) | (ids == c2)).all()), (sign, c1, c2, ids[:8].tolist())
+
+
 @pytest.mark.parametrize("src_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,K,extra", [(1, 32, 0), (37, 288, 3), (8192, 768, 0), (50260, 768, 44), (300, 2048, 0)])
 def test_pack_kpanels(src_dtype, rows, K, extra):

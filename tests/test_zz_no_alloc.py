@@ -72,3 +72,31 @@ def test_colsum_static_rejects_oversize():
     assert b"built-in buffer" in lib.capdec_last_error()
     torch.cuda.synchronize()
     assert bool((out == 3.0).all())                    # nothing was launched
+
+
+def test_colsum_static_under_graph_capture():
+    """What the entry point is for: after one ordinary call on the device (which resolves the array's address), the
+    call is recorded into a HIP graph and the graph replayed on fresh inputs, twice."""
+    lib = _bind()
+    dev = torch.device("cuda:0")
+    M, N = 640, 768
+    x = torch.randn(M, N, device=dev)
+    got = torch.empty(N, dtype=torch.float32, device=dev)
+    assert _static(lib, x, got) == 0                    # outside capture: first use on this device
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = _static(lib, x, got)
+    assert rc == 0, lib.capdec_last_error()
+    want = torch.empty(N, dtype=torch.float32, device=dev)
+    for seed in (1, 2):
+        x.copy_(torch.randn(M, N, device=dev, generator=torch.Generator(device=dev).manual_seed(seed)))
+        got.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ops.colsum(x, want)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)

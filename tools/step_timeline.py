@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Timeline of the last training step in a rocprofv3 kernel trace (the *_kernel_trace.csv of
-`rocprofv3 --kernel-trace -- python3 bench.py --steps K ...`): every launch with its start relative to the
-step's first kernel, its duration, its queue, and the gap since the previous kernel ended on any queue.
-Usage: python tools/step_timeline.py <kernel_trace.csv>"""
+`rocprofv3 --kernel-trace -- python3 bench.py --steps K --stage-steps 0 ...`: without --stage-steps 0 the trace ends
+with bench.py's five untimed steps that bracket every stage with events, whose brackets leave the device idle between
+stages): every launch with its start relative to the step's first kernel, its duration, its queue, and the gap since the
+previous kernel ended on any queue.
+Usage: python tools/step_timeline.py <kernel_trace.csv> [steps back from the end, default 2: the last step may be cut short]"""
 import csv
 import re
 import sys
@@ -27,7 +29,10 @@ def main():
     ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 8]
     if len(ends) < 2:
         raise SystemExit("fewer than two steps found")
-    a, b = ends[-2] + 1, ends[-1] + 1
+    back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    if len(ends) < back + 1:
+        raise SystemExit("not enough steps in the trace")
+    a, b = ends[-back - 1] + 1, ends[-back] + 1
     b = min(b, len(rows) - 1)
     step = rows[a:b]
     t0 = step[0][0]
