@@ -1543,8 +1543,18 @@ int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
 // (the 32 rows of a slot are 512 contiguous bytes), and the first 32 threads merge the 32 groups in a
 // fixed order (deterministic).  32 rows per block puts 256 blocks on the chip at 8192 rows.
 struct RowFold { float m1; int a1; float m2; float s; };
-__device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2, float ps) {
-    if (pm > t.m1 || (pm == t.m1 && pa < t.a1)) {
+// Which of two slot maxima leads.  PACKED: the records come from the persistent kernel, whose maxima carry their column
+// inside the slot in the low 6 mantissa bits -- values are compared without those bits (so that equal logits in
+// different slots are equal here, whatever their position in the slot), ties go to the lower column.
+__device__ __forceinline__ bool leads(float pm, int pa, float m1, int a1, bool packed) {
+    if (packed) {
+        pm = __uint_as_float(__float_as_uint(pm) & 0xFFFFFFC0u);
+        m1 = __uint_as_float(__float_as_uint(m1) & 0xFFFFFFC0u);
+    }
+    return pm > m1 || (pm == m1 && pa < a1);
+}
+__device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2, float ps, bool packed) {
+    if (leads(pm, pa, t.m1, t.a1, packed)) {
         t.s = t.s * (t.m1 > -INFINITY ? __expf(t.m1 - pm) : 0.f) + ps;
         t.m2 = fmaxf(t.m1, p2); t.m1 = pm; t.a1 = pa;
     } else {
@@ -1553,7 +1563,7 @@ __device__ __forceinline__ void fold_push(RowFold& t, float pm, int pa, float p2
     }
 }
 __device__ __forceinline__ void fold_push_ref(RowFold& t, float pm, int pa, float p2, float ps) {
-    if (pm > t.m1 || (pm == t.m1 && pa < t.a1)) { t.m2 = fmaxf(t.m1, p2); t.m1 = pm; t.a1 = pa; }
+    if (leads(pm, pa, t.m1, t.a1, true)) { t.m2 = fmaxf(t.m1, p2); t.m1 = pm; t.a1 = pa; }
     else t.m2 = fmaxf(t.m2, pm);
     t.s += ps;
 }
@@ -1572,7 +1582,7 @@ template <bool REF>
 __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, const float* zlabel, const int64_t* labels,
                                                            int ce_B, int ce_L, long M, int np,
                                                            float* lse_out, int32_t* argmax_out, int64_t* ids_out, float* margin_out,
-                                                           float* rowloss, int32_t* rowcorrect, LabelDot dot, int32_t* rowflag) {
+                                                           float* rowloss, int32_t* rowcorrect, LabelDot dot, int32_t* rowflag, int packed) {
     __shared__ RowFold sh[FIN_GROUPS][FIN_ROWS];
     __shared__ float zdot[FIN_GROUPS][FIN_ROWS + 1];
     const int r = threadIdx.x & (FIN_ROWS - 1), w = threadIdx.x / FIN_ROWS;
@@ -1614,7 +1624,7 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
             for (int u = 0; u < FIN_UNROLL; ++u)
                 if (sl + u * FIN_GROUPS < np) {
                     if constexpr (REF) fold_push_ref(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
-                    else fold_push(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1]);
+                    else fold_push(t, q[u][0], __float_as_int(q[u][3]), q[u][2], q[u][1], packed != 0);
                 }
         }
     }
@@ -1625,7 +1635,7 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const f32x4* part4, c
         for (int i = 1; i < FIN_GROUPS; ++i) {
             const RowFold o = sh[i][r];
             if constexpr (REF) fold_push_ref(t, o.m1, o.a1, o.m2, o.s);
-            else fold_push(t, o.m1, o.a1, o.m2, o.s);
+            else fold_push(t, o.m1, o.a1, o.m2, o.s, packed != 0);
         }
         const float lse = REF ? zlabel[m] + logf(t.s) : t.m1 + logf(t.s);
         if constexpr (REF) rowflag[m] = (t.m1 > CE_REF_LIMIT || !(t.s < 3.0e38f)) ? 1 : 0;
@@ -2334,7 +2344,7 @@ extern "C" int capdec_logits_ce_fwd(const void* h, const void* W, const float* b
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel<false>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, labels, B, L, M, ws.np,
-                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, dot, (int32_t*)nullptr);
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, dot, (int32_t*)nullptr, geo >= 0 ? 1 : 0);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
@@ -2375,7 +2385,7 @@ extern "C" int capdec_logits_ce_fwd_ref(const void* h, const void* W, const floa
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel<true>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, (const float*)rowref, labels, B, L, M, ws.np,
-                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, LabelDot{}, ws.rowflag);
+                       lse, argmax, (int64_t*)nullptr, (float*)nullptr, ws.rowloss, ws.rowcorrect, LabelDot{}, ws.rowflag, 1);
     hipLaunchKernelGGL(ce_ref_fixup_kernel, dim3((unsigned)((M + FIX_ROWS - 1) / FIX_ROWS)), dim3(256), 0, st, (const int32_t*)ws.rowflag, M, (const bf16_t*)h, ldh,
                        (const bf16_t*)W, ldw, bias, d, V, (bf16_t*)probs, ld_probs, prows, rowref, lse, ws.rowloss);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, ws.rowloss, ws.rowcorrect, M, loss_sum, correct);
@@ -2426,7 +2436,7 @@ extern "C" int capdec_logits_argmax(const void* h, const void* W, const float* b
     if (rc) return rc;
     hipLaunchKernelGGL(ce_finalize_kernel<false>, dim3((unsigned)((M + FIN_ROWS - 1) / FIN_ROWS)), dim3(1024), 0, st,
                        ws.part4, ws.zlabel, (const int64_t*)nullptr, 1, 1, M, ws.np,
-                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr, LabelDot{}, (int32_t*)nullptr);
+                       (float*)nullptr, (int32_t*)nullptr, out_ids, margin, (float*)nullptr, (int32_t*)nullptr, LabelDot{}, (int32_t*)nullptr, geo >= 0 ? 1 : 0);
     CAPDEC_LAUNCH_CHECK();
     return CAPDEC_OK;
 }

@@ -76,10 +76,19 @@ def _worker(rank, world, port, dtype_name, q, batch=6, dropout=0.0, backend="glo
             want, ref_losses, _, _ = train(0, sh.B, False)
             tol = 2e-6 if dtype == torch.float32 else 2e-3
             if compress == "bf16":
-                # gradients rounded to bfloat16 (relative 2^-9) before the sum: Adam's first two updates are
-                # lr * g / (|g| + eps)-like, so a parameter moves by at most 2 * lr = 2e-3 in all and the rounding
-                # changes that by at most 2 * lr * 2^-8 = 8e-6; the bound is on the parameter DIFFERENCE against the f32 exchange
-                tol = 5e-5
+                # Adam normalises: where the two ranks' gradients nearly cancel, rounding them to bfloat16 (2^-9 relative)
+                # before the sum can flip the sign of the sum, and the parameter then moves by lr the other way -- no
+                # element-wise bound below 2 * lr * steps holds.  What is bounded is the direction of each tensor's update
+                # (cosine against the f32 exchange's update) and its size.
+                for k in want:
+                    du, dw = (got[k] - sd[k]).double().flatten(), (want[k] - sd[k]).double().flatten()
+                    if float(dw.norm()) == 0.0:
+                        continue
+                    c = float(du @ dw / (du.norm() * dw.norm() + 1e-30))
+                    if c < 0.98 or float((du - dw).abs().max()) > 2 * 2 * 1e-3 * 1.05:
+                        msg = f"update of {k}: cosine {c:.4f} against the f32 exchange, max difference {float((du - dw).abs().max()):.2e}"
+                        break
+                want = {}
             for k in want:
                 err = (got[k] - want[k]).abs().max().item()
                 if err > tol * (want[k].abs().max().item() + 1.0):
@@ -113,8 +122,9 @@ def test_two_rank_training_matches_single_process(dtype_name, batch, dropout):
 
 
 def test_two_rank_training_with_bf16_gradient_exchange():
-    """GradReducer(compress="bf16"): parameters after two steps stay within the stated bound of single-process
-    training (whose gradients never leave f32), and several buckets were exchanged."""
+    """GradReducer(compress="bf16"): after two steps every tensor's UPDATE points the way single-process training's
+    does (cosine >= 0.98; its gradients never leave f32) and no element is further off than two Adam steps can
+    carry it; several buckets were exchanged."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29810 + (os.getpid() % 40)
