@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--stage-steps", type=int, default=5,
                     help="extra untimed steps with an event bracket around every stage, after the timed ones (0: none, so that a "
                          "kernel trace of the run ends with the timed steps)")
+    ap.add_argument("--no-yardstick", action="store_true", help="skip the vendor-library product timed beside the dominant kernel")
     ap.add_argument("--no-greedy", action="store_true")
     ap.add_argument("--no-scaled", action="store_true", help="skip the 12-block / 257-patch leg")
     ap.add_argument("--no-global-2048", action="store_true", help="skip the fixed-global-batch-2048 leg")
@@ -260,6 +261,32 @@ def head_roofline(spans, steps, B, slab, dtype):
     return per_kernel, hbm_kernels
 
 
+def library_yardstick(dev, B):
+    """What the vendor library reaches on the dominant kernel's product alone (torch.matmul -> hipBLASLt, bf16 output, no
+    bias, no loss, same operands' shapes and value distribution): a yardstick beside `roofline`, not a product path --
+    nothing in image_caption_amd calls torch.matmul."""
+    try:
+        M, d, V = 32 * B, 768, 50260
+        g = torch.Generator(device=dev).manual_seed(0)
+        h = torch.randn(M, d, device=dev, generator=g).to(torch.bfloat16)
+        w = (torch.randn(V, d, device=dev, generator=g) * 0.03).to(torch.bfloat16)
+        out = torch.empty(M, V, device=dev, dtype=torch.bfloat16)
+        for _ in range(5):
+            torch.matmul(h, w.t(), out=out)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(20):
+            torch.matmul(h, w.t(), out=out)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 20
+        return {"what": f"torch.matmul (hipBLASLt) {M}x{V}x{d}, bf16 output, no bias / loss / argmax, run alone back to back",
+                "ms_per_launch": round(ms, 4), "tflops": round(2.0 * M * d * V / (ms * 1e-3) / 1e12, 1)}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": str(ex)[:120]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -436,6 +463,8 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and not args.no_scaled and args.n_blocks == 1:
             result["scaled"] = scaled_bench(build, timed, args)
+        if world == 1 and roofline is not None and not args.no_yardstick and args.dtype == "bf16":
+            roofline["library_yardstick"] = library_yardstick(dev, B)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), file=json_out, flush=True)

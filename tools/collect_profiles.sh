@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 rm -rf $O/pcol && mkdir -p $O/pcol
 cd $R
-COMMON="--no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --stage-steps 0"
+COMMON="--no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0"
 timeout -k 10 300 python bench.py > $O/bench_${V}.log 2>&1
 # the kernel-trace run prints a bench line of its own (same process as the trace): the agreement check below uses THAT line
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pcol/ks -o ks -- python3 bench.py --steps 20 --warmup 5 $COMMON > $O/bench_traced_${V}.log 2>&1

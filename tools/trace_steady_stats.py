@@ -51,7 +51,8 @@ def main():
                 line = json.loads(l)
         if line and line.get("roofline"):
             want = line["roofline"]["ms_per_launch"] * 1e3
-            got = [sum(v) / len(v) for n, v in agg.items() if n.startswith("head_fwd_kernel")]
+            # the training forward is the instantiation with the longest launches (the others are the block's forward products)
+            got = sorted((sum(v) / len(v) for n, v in agg.items() if n.startswith("head_fwd_kernel")), reverse=True)
             if got:
                 dev = abs(got[0] - want) / want
                 print(f"# head_fwd_kernel: trace average {got[0]:.1f} us, bench line roofline.ms_per_launch {want:.1f} us, difference {dev * 100:.1f} %")
