@@ -1392,6 +1392,13 @@ int g_extra_lds = 0;                 // diagnostic: LDS bytes added to every rin
 long g_dbg_a_panel = 0;  // diagnostic: the next 256x256 pipelined launches read A as a column-panel image with this many rows per panel
 int g_route_small = 1;   // the two routing rules for short products below (diagnostic hook capdecdbg_gemm_route_small: 0 = without)
 int g_gemm_mode = 0;     // diagnostic: force a kernel (1 register-staged, 2 ring 128x128, 3 ring 256x128 8 waves, 4 ring 256x128 4 waves, 5 ring 256x256, 6 pipelined 256x256, 7 pipelined 256x128)
+int g_ppipe = 1;         // the persistent pipelined kernel takes the products it pays for (diagnostic hook capdecdbg_gemm_ppipe: 0 = never)
+// where the persistent pipelined kernel is the faster choice: at least two full rounds of 256x256 tiles on the 256 CUs
+// (a workgroup's ring then runs across several tiles) and a reduction of at least 512
+static bool ppipe_pays(const GemmArgs& a) {
+    const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    return tiles >= 512 && a.K >= 512;
+}
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a_in, int in_dtype, hipStream_t st) {
@@ -2012,6 +2019,7 @@ extern "C" void capdecdbg_gemm_stamps(void* device_buffer) { g_stamps = (unsigne
 extern "C" void capdecdbg_gemm_mode(int mode) { g_gemm_mode = mode; }
 extern "C" void capdecdbg_gemm_a_panel(long rows) { g_dbg_a_panel = rows; }
 extern "C" void capdecdbg_gemm_route_small(int on) { g_route_small = on; }
+extern "C" void capdecdbg_gemm_ppipe(int on) { g_ppipe = on; }
 extern "C" void capdecdbg_gemm_extra_lds(int bytes) { g_extra_lds = bytes > 0 ? bytes : 0; }
 
 // ==================================================================== C ABI
@@ -2193,6 +2201,25 @@ static int gemm_bias_act_impl(const capdec_gemm_desc* d, void* stream) {
             if (d->row_scale) t_row_scaled = true;
             return CAPDEC_OK;
         }
+    }
+    // The large data gradients dY W of a stack (row-major dY, the weight read along its output index: reduction-major second
+    // operand, plain bf16 result, at least two rounds of 256x256 tiles): the persistent pipelined kernel of ppipe.hip -- the
+    // 4-wave / 128x128 main loop of the pipelined kernel below, the persistent ring and register epilogue of head_fwd.hip.
+    // Diagnostic mode 12 forces it wherever it is supported (also on a row-major second operand with a forward epilogue:
+    // measured level with the eight-wave persistent kernel below, so not routed), capdecdbg_gemm_ppipe(0) switches it off.
+    if (d->in_dtype == CAPDEC_BF16 && a.out_dtype == CAPDEC_BF16 && !a.a_kmajor && !a.residual && !a.accumulate && a.gate_mode == CAPDEC_GATE_NONE &&
+        !a.aux_out && !a.colsum && !a.kv_cache && !a.kvec && !a.kvec_out && !d->row_scale && !a.a_panel &&
+        (a.act == CAPDEC_ACT_NONE || a.act == CAPDEC_ACT_RELU) &&
+        (g_gemm_mode == 12 || (g_gemm_mode == 0 && g_ppipe && a.b_kmajor && ppipe_pays(a)))) {
+        HeadFwdArgs ha = {};
+        ha.A = (const bf16_t*)a.A; ha.B = (const bf16_t*)a.B; ha.bias = a.bias; ha.C = (bf16_t*)a.C;
+        ha.lda = a.lda; ha.ldb = a.ldb; ha.ldc = a.ldc; ha.M = a.M; ha.N = a.N; ha.K = a.K; ha.store_cols = a.N;
+        ha.b_tr = a.b_kmajor; ha.mode = 1;
+        ha.col_scale = a.col_scale_n > 0 ? a.col_scale : 1.f; ha.col_scale_n = a.col_scale_n;
+        ha.relu = a.act == CAPDEC_ACT_RELU;
+        ha.drop_thr = a.drop_thr; ha.drop_k0 = a.drop_k0; ha.drop_k1 = a.drop_k1; ha.drop_scale = a.drop_scale;
+        if (d->b_panels && !a.b_kmajor) { ha.Bp = (const bf16_t*)d->b_panels; ha.b_rows = d->b_panel_rows; }
+        if (ppipe_supported(ha)) return ppipe_launch(ha, (hipStream_t)stream);
     }
     // Large row-major bf16 products with nothing but bias / column scale / ReLU / dropout behind them (the in_proj and
     // linear1 forwards of a stack at full batch) go to the persistent kernel of head_fwd.hip: one operand ring for the

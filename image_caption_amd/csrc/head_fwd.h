@@ -34,8 +34,14 @@ struct HeadFwdArgs {
     long c_panel_rows;                   // modes 0 / 3: > 0: C is written as a column-panel image [ldc / 32][c_panel_rows][32] (ldc % 32 == 0)
     // filled by head_fwd_launch: bytes from one k-step's columns to the next, and by how much a view shrinks per k-step
     long kstepA, kstepB; int remdecA, remdecB;
+    int b_tr;                            // ppipe only: B is reduction-major [K, ldb] (the weight of a data gradient, read along its output index)
 };
 
 // geometry 0: 256x128 tiles, 4 waves, two workgroups per CU; 1: 256x256 tiles, 8 waves, one workgroup per CU
 bool head_fwd_supported(const HeadFwdArgs& a);
 int head_fwd_launch(const HeadFwdArgs& a, int geometry, hipStream_t st);
+
+// The persistent pipelined kernel (ppipe.hip): 256x256 tiles, 4 waves of 128x128, mode 1 only; B row-major (or its
+// k-panel image) or, with b_tr, reduction-major.
+bool ppipe_supported(const HeadFwdArgs& a);
+int ppipe_launch(const HeadFwdArgs& a, hipStream_t st);

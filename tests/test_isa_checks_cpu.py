@@ -18,6 +18,7 @@ def test_no_instruction_touches_an_inflight_fragment_register():
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "gemm_bf16_pipe_kernel" in r.stdout          # the kernels with inline-assembly reads were found and walked
+    assert "ppipe_kernel" in r.stdout and "gemm_dev.s: no scratch instruction inside an MFMA loop" in r.stdout
 
 
 def _run_checker(tmp_path, body):
@@ -44,3 +45,17 @@ def test_checker_finds_a_reused_register_and_follows_branches(tmp_path):
     assert r.returncode == 1
     r = _run_checker(tmp_path, "\tds_read_b128 v[4:7], v12\n\tv_mov_b32_e32 v5, v3\n" + read + "\ts_waitcnt lgkmcnt(0)\n")
     assert r.returncode == 0
+
+
+def test_mfma_loop_checker_finds_a_spill_inside_the_loop(tmp_path):
+    """tools/check_mfma_loops.py: a scratch instruction inside a loop of MFMAs is reported, one outside is not."""
+    import sys
+    mf = "".join("\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n" for _ in range(16))
+    tool = os.path.join(ROOT, "tools", "check_mfma_loops.py")
+    for spill_inside, want in ((True, 1), (False, 0)):
+        body = "_Z6kernelv:\n\tscratch_store_dword off, v1, off\n.LBB0_1:\n" + mf + ("\tscratch_load_dword v1, off, off\n" if spill_inside else "") + \
+               "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
+        src = tmp_path / f"k{want}.s"
+        src.write_text(body)
+        r = subprocess.run([sys.executable, tool, str(src)], capture_output=True, text=True)
+        assert r.returncode == want, r.stdout

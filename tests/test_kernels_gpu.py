@@ -123,10 +123,11 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     (300, 2304, 288, False, 0.2, 768),        # column scale on the first 768 columns (the query part of in_proj), 9 k-steps
     (8192, 2304, 768, True, 0.1, 768),        # more tiles than workgroups
 ])
-@pytest.mark.parametrize("pmode", [10, 11])           # 256x256 and 256x128 tiles
+@pytest.mark.parametrize("pmode", [10, 11, 12])       # 256x256 and 256x128 tiles of the ring kernel; the pipelined persistent kernel
 def test_persistent_standard_epilogue(gemm_mode, pmode, M, N, K, relu, p, scale_n):
-    """The persistent kernel's bias / column-scale / ReLU / dropout epilogue (modes 10 / 11 force it) against the tile
-    kernels (mode 4) and torch: same dropout mask element for element, values within bf16 rounding."""
+    """The persistent kernels' bias / column-scale / ReLU / dropout epilogue (modes 10 / 11 / 12 force them; 12 leaves a
+    reduction that is not a multiple of 64 to the others) against the tile kernels (mode 4) and torch: same dropout mask
+    element for element, values within bf16 rounding."""
     A = rnd(M, K, dtype=torch.bfloat16, seed=95)
     B = rnd(N, K, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=96)
     bias = rnd(N, seed=97)
@@ -156,7 +157,7 @@ def test_persistent_standard_epilogue(gemm_mode, pmode, M, N, K, relu, p, scale_
     close(outs[0], outs[1], 1e-2, "persistent vs tile kernel")
 
 
-@pytest.mark.parametrize("mode", [10, 11])            # 256x256 and 256x128 tiles of the persistent kernel
+@pytest.mark.parametrize("mode", [10, 11, 12])        # 256x256 and 256x128 tiles of the persistent ring kernel; the pipelined one
 @pytest.mark.parametrize("M,N,K,p", [
     (515, 768, 768, 0.1),            # out_proj shape: three column tiles, ragged rows
     (1000, 260, 2048, 0.0),          # N a multiple of 4 only, deep reduction (linear2)
@@ -183,6 +184,86 @@ def test_persistent_residual_epilogue(gemm_mode, mode, M, N, K, p):
         assert torch.equal((outs[0] - res).abs() > 1e-7, kept)       # the same mask, element for element
     close(outs[0], ref, 1.5e-2, "persistent vs torch")
     close(outs[0], outs[1], 1e-3, "persistent vs tile kernel")
+
+
+@pytest.mark.parametrize("M,N,K,what", [
+    (20000, 2304, 768, "fwd"),        # 79 x 9 = 711 tiles: every workgroup walks two or three, the last row tile ragged
+    (20000, 2304, 768, "fwd_image"),  # ... with the weight read as its k-panel image
+    (20000, 768, 2304, "dgrad"),      # data gradient dY W: reduction-major second operand, 72 k-steps
+    (20000, 2048, 768, "dgrad"),
+    (300, 256, 256, "dgrad"),         # one tile column, the minimum of 8 k-steps, fewer tiles than workgroups
+])
+def test_pipelined_persistent_kernel(gemm_mode, M, N, K, what):
+    """The persistent pipelined kernel (mode 12 forces it) on the shapes it is routed: forward epilogues on a row-major
+    weight or its k-panel image, and plain data gradients on a reduction-major weight, against torch f32 products of the
+    same bf16 operands and against the tile kernels (mode 4); twice in a row (the ring state of a launch must not leak)."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=111)
+    drop = ops.dropout_keys(3, 4, 5, 0.1)
+    cs = None
+    if what in ("dgrad", "relu_gate", "gelu_gate"):
+        W = rnd(K, N, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=112)       # [out = K of the product, in = N]
+        ref = A.float() @ W.float()
+        make = lambda: torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)   # noqa: E731
+        tol = 1e-2
+        if what == "dgrad":
+            run = lambda out: ops.gemm(A, W, out, M=M, N=N, K=K, b_kmajor=True)         # noqa: E731
+        else:
+            ws = torch.empty((M + 63) // 64 * N * 4, dtype=torch.uint8, device=DEV)
+            cs = torch.zeros(N, device=DEV)
+            if what == "relu_gate":
+                gate = torch.relu(rnd(M, N, seed=115)).to(torch.bfloat16)
+                ref = ref * (gate.float() != 0) / 0.9
+                gmode = _lib.GATE_RELU_OUT
+            else:
+                gate = rnd(M, N, seed=115).to(torch.bfloat16)
+                keep = ops.dropout_mask(drop, M * N, DEV).reshape(M, N)
+                zf = gate.float().requires_grad_(True)
+                torch.nn.functional.gelu(zf).sum().backward()
+                ref = ref * zf.grad * keep / 0.9
+                gmode = _lib.GATE_GELU_PRE
+
+            def run(out):
+                cs.zero_()
+                ops.gemm(A, W, out, M=M, N=N, K=K, b_kmajor=True, gate=gate, gate_mode=gmode, gate_drop=drop, colsum=cs, workspace=ws)
+    else:
+        W = rnd(N, K, dtype=torch.bfloat16, scale=2.0 / math.sqrt(K), seed=112)
+        bias = rnd(N, seed=113)
+        z = A.float() @ W.float().t() + bias
+        if what == "res":
+            res = rnd(M, N, seed=114)
+            run = lambda out: ops.gemm(A, W, out, bias=bias, drop=drop, residual=res)   # noqa: E731
+            make = lambda: torch.full((M, N), float("nan"), device=DEV)                 # noqa: E731
+        else:
+            panels = ops.pack_kpanels(W, torch.empty(ops.kpanel_shape(N, K), device=DEV, dtype=torch.bfloat16)) if what == "fwd_image" else None
+            run = lambda out: ops.gemm(A, W, out, bias=bias, act=_lib.ACT_RELU, drop=drop, col_scale=0.5, col_scale_n=768, b_panels=panels)   # noqa: E731
+            make = lambda: torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)   # noqa: E731
+            z[:, :768] *= 0.5
+            z = torch.relu(z)
+        tol = 1.5e-2
+    outs = []
+    for mode in (12, 12, 4):
+        out = make()
+        gemm_mode(mode)
+        run(out)
+        gemm_mode(0)
+        outs.append(out.float())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1])
+    if what in ("dgrad", "relu_gate", "gelu_gate"):
+        close(outs[0], ref, tol, "pipelined persistent vs torch")
+        if cs is not None:
+            gemm_mode(12)
+            run(make())
+            gemm_mode(0)
+            close(cs, ref.sum(0), 6e-2, "column sums of the gated product")
+    else:
+        base = res if what == "res" else torch.zeros_like(z)
+        kept = (outs[2] - base).abs() > 1e-7
+        ref = base + torch.where(kept, z / 0.9, torch.zeros_like(z))
+        nz = z != 0
+        assert torch.equal(((outs[0] - base).abs() > 1e-7) & nz, kept & nz)     # the same dropout mask, element for element
+        close(outs[0], ref, tol, "pipelined persistent vs torch")
+    close(outs[0], outs[2], 1e-2 if what != "res" else 1e-3, "pipelined persistent vs tile kernel")
 
 
 @pytest.mark.parametrize("mode", [8, 9])              # the two tile geometries of the persistent forward kernel
@@ -767,7 +848,7 @@ def test_gemm_gates(dtype, tol):
             assert torch.equal(runs[0], runs[1])
 
 
-@pytest.mark.parametrize("mode", [0, 4, 7])
+@pytest.mark.parametrize("mode", [0, 4, 7, 12])
 def test_gated_dgrad_every_geometry(gemm_mode, mode):
     """The data gradient through linear2 and the ReLU gate as the engine launches it (W reduction-major, gate and dropout
     applied in the epilogue, bias-gradient column sums through the workspace), on the ring and the pipelined kernels."""

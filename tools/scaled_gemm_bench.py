@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the GEMM shapes of one block of the 12-block / 257-patch configuration at batch 256
 (74240 rows): forward, data-gradient and weight-gradient products, each as the engine launches it.
-Usage (on the GPU box): python tools/scaled_gemm_bench.py [reps] [gemm mode]"""
+Usage (on the GPU box): python tools/scaled_gemm_bench.py [reps] [gemm mode] [0: without the persistent pipelined kernel]"""
 import ctypes
 import os
 import sys
@@ -34,6 +34,10 @@ def main():
     lib = _lib.load()
     lib.capdecdbg_gemm_mode.argtypes = [ctypes.c_int]
     lib.capdecdbg_gemm_mode.restype = None
+    lib.capdecdbg_gemm_ppipe.argtypes = [ctypes.c_int]
+    lib.capdecdbg_gemm_ppipe.restype = None
+    ppipe = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    lib.capdecdbg_gemm_ppipe(ppipe)
     B, S, d, ff = 256, 290, 768, 2048
     M = S * B
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -68,13 +72,14 @@ def main():
     add("dgrad linear2 + relu gate N=2048 K=768", 2.0 * M * ff * d,
         lambda: ops.gemm(x, w2, da1, M=M, N=ff, K=d, b_kmajor=True, gate=a1, gate_mode=_lib.GATE_RELU_OUT, gate_drop=drop))
     add("dgrad linear1   N=768 K=2048 (f32 out)", 2.0 * M * ff * d, lambda: ops.gemm(a1, w1, dxf, M=M, N=d, K=ff, b_kmajor=True))
+    add("dgrad linear1   N=768 K=2048 (bf16 out)", 2.0 * M * ff * d, lambda: ops.gemm(a1, w1, dx, M=M, N=d, K=ff, b_kmajor=True))
     # weight gradients: dW = dY^T . X, both operands reduction-major, split-K
     gw_in, gw_o, gw1, gw2 = [torch.empty_like(w, dtype=torch.float32) for w in (w_in, w_o, w1, w2)]
     add("wgrad in_proj   3d x d  K=74240    ", 2.0 * M * 3 * d * d, lambda: ops.gemm(qkv, x, gw_in, M=3 * d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
     add("wgrad out_proj  d x d   K=74240    ", 2.0 * M * d * d, lambda: ops.gemm(x, x, gw_o, M=d, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
     add("wgrad linear1   ff x d  K=74240    ", 2.0 * M * ff * d, lambda: ops.gemm(a1, x, gw1, M=ff, N=d, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
     add("wgrad linear2   d x ff  K=74240    ", 2.0 * M * ff * d, lambda: ops.gemm(x, a1, gw2, M=d, N=ff, K=M, a_kmajor=True, b_kmajor=True, workspace=skws))
-    print(f"gemm mode {mode}")
+    print(f"gemm mode {mode}, persistent pipelined kernel {'on' if ppipe else 'off'}")
     tot = 0.0
     for name, ms, tf in rows:
         tot += ms
