@@ -300,6 +300,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    from image_caption_amd.dp import init_process_group as dp_init
     rehearse = world == 1 and os.environ.get("CAPDEC_DP_SINGLE_RANK", "0") == "1"
     json_out = sys.stdout
     if world > 1 or rehearse:
@@ -311,9 +312,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            dp_init("nccl", dev, rank=0, world_size=1)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dp_init("nccl", dev)
 
     from image_caption_amd.decoder import CaptionTrainer, TransformerDecoder
     from image_caption_amd.engine import EngineOptions, KernelTimer

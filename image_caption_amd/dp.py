@@ -179,6 +179,26 @@ class GradReducer:
         self.works = []
 
 
+def init_process_group(backend: str = "nccl", device: Optional[torch.device] = None, high_priority: bool = True, **kw):
+    """``torch.distributed.init_process_group`` for one process per GPU, with the communicator's stream created at
+    the highest stream priority when the backend is RCCL ("nccl"): the large products of the backward launch one
+    workgroup per CU, and a collective's workgroups only start on a CU between two of those, so they should be first
+    in line when one retires.  ``CAPDEC_RCCL_HIGH_PRIORITY=0`` (or ``high_priority=False``) asks for the default
+    priority; a torch build without the option falls back to it."""
+    if device is not None and device.type == "cuda":
+        kw.setdefault("device_id", device)
+    want = high_priority and backend == "nccl" and os.environ.get("CAPDEC_RCCL_HIGH_PRIORITY", "1") != "0"
+    if want:
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except (AttributeError, TypeError):
+            opts = None
+        if opts is not None:
+            kw.setdefault("pg_options", opts)
+    dist.init_process_group(backend, **kw)
+    return dist.group.WORLD
+
+
 def shard_range(n: int, rank: int, world: int):
     """Contiguous slice [lo, hi) of n samples owned by `rank` (remainder spread over
     the first ranks).  Samples are independent along dim 1 of decoder_inputs /

@@ -1,0 +1,23 @@
+#!/bin/bash
+# The A/B and yardstick logs of this round that DESIGN.md cites, in one call on one box (results in gpurun_out/; copy to profiles/).
+#   bash tools/collect_evidence_r03.sh
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+{ echo "# tools/head_power_probe.py"; timeout -k 10 300 python tools/head_power_probe.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_head_power_probe.log
+{ echo "# tools/blas_probe.py (torch.matmul -> hipBLASLt; nothing in the package calls it)"; timeout -k 10 200 python tools/blas_probe.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_vendor_blas_probe.log
+{ echo "# tools/scaled_gemm_bench.py 10 0 <0|1>: the block's products at 74240 rows, persistent pipelined kernel off / on; mode 12 forces it on every product it supports";
+  for a in "0 0" "0 1" "12 1" "0 0" "0 1"; do timeout -k 10 120 python tools/scaled_gemm_bench.py 10 $a 2>&1 | grep -v amdgpu.ids; done; } > $O/r03_ppipe_gemm_microbench.log
+{ echo "# bench.py --scaled-only --stage-steps 0 [--no-ppipe] [--no-wgrad-stream], alternating";
+  for i in 1 2 3; do
+    echo "default:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+    echo "--no-ppipe:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 --no-ppipe 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+    echo "--no-wgrad-stream:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 --no-wgrad-stream 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  done; } > $O/r03_scaled_step_ab.log
+{ echo "# CAPDEC_DP_SINGLE_RANK=1 python tools/dp_bucket_timing.py [--compress bf16]";
+  timeout -k 10 120 python tools/dp_bucket_timing.py 2>/dev/null; timeout -k 10 120 python tools/dp_bucket_timing.py --compress bf16 2>/dev/null; } > $O/r03_dp_bucket_timing.log
+{ echo "# bench.py with and without event brackets inside the timed steps (--no-spans), alternating";
+  for i in 1 2 3; do
+    echo "default:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1
+    echo "--no-spans:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0 --no-spans 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1
+  done; } > $O/r03_bench_brackets_ab.log
+tail -3 $O/r03_scaled_step_ab.log $O/r03_dp_bucket_timing.log $O/r03_bench_brackets_ab.log

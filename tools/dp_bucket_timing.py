@@ -31,7 +31,8 @@ def main():
     sys.stdout.flush()
     out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)                                   # RCCL's banner goes to descriptor 1
-    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    from image_caption_amd.dp import init_process_group as dp_init
+    dp_init("nccl", dev, rank=0, world_size=1)
     from image_caption_amd.decoder import CaptionTrainer, TransformerDecoder
     from image_caption_amd.engine import EngineOptions
     from image_caption_amd.synthetic import make_batch
