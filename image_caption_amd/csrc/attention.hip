@@ -170,6 +170,11 @@ __device__ __forceinline__ void frags_from_global(const bf16_t* base, long sstri
 }
 
 // row-major MFMA operand: lane (g,i) gets M[row0+i][k0 + 8g .. +7]
+// First statement of a block that only some key / query blocks need (masking): keeps the block a branch.  Left to its
+// cost model the compiler turns such a block into selects that every pass of the loop executes -- a quarter of the vector
+// instructions of the attention loops, for a mask that four blocks in five do not need.
+__device__ __forceinline__ void masked_path() { asm volatile(""); }
+
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int k0, int lane) {
     return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * Geo<HD>::ROWB + (k0 + 8 * (lane >> 4)) * 2);
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : 3) vo
         }
         // masking only in key blocks that some query of the wave does not see entirely (a wave-uniform test)
         if (kb + 64 > klim_wave) {
+            masked_path();
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -622,14 +628,16 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
             bool keep[4] = {true, true, true, true};
             if (p.drop_thr) dropout_keep4(p.drop_k0, p.drop_k1, idx_row + kb + t * 16 + 4 * g, p.drop_thr, keep);
             const bool masked = kb + 64 > klim_wave;          // wave-uniform: some query of the wave does not see the whole block
-            float dsv[4];
+            float dsv[4], pv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nlse2));
-                if (masked) pv = kb + t * 16 + 4 * g + r < klim ? pv : 0.f;
-                const float dpv = keep[r] ? dp[r] * p.drop_scale : 0.f;
-                dsv[r] = pv * (dpv - delta);
+            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nlse2));
+            if (masked) {
+                masked_path();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = kb + t * 16 + 4 * g + r < klim ? pv[r] : 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsv[r] = pv[r] * (fmaf(keep[r] ? dp[r] : 0.f, p.drop_scale, -delta));
             dsu[t >> 1][(t & 1) * 2 + 0] = pack_bf16(dsv[0], dsv[1]);
             dsu[t >> 1][(t & 1) * 2 + 1] = pack_bf16(dsv[2], dsv[3]);
         }
@@ -670,10 +678,13 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
 }
 
 // ================================================================== backward: dK, dV (key-major)
-// SEQ = true: one workgroup of 8 waves per (sequence, head) walks ALL key tiles (wave, wave + 8, ...), so Q and dO
-// are staged once per head instead of once per 64-key slab.
+// SEQ = true: one workgroup per (sequence, head) walks ALL key tiles (wave, wave + nwaves, ...), so Q and dO are staged
+// once per head instead of once per 64-key slab.  Twelve waves where the registers allow three per SIMD (head width up
+// to 96: 162 registers), eight otherwise: the loop is bound by its vector arithmetic (55 % of SIMD cycles against 20 % on
+// the matrix pipe, by the counters), and a third wave per SIMD lets more of the two overlap (317 -> 297 us at S = 290).
+template <int HD> constexpr int dkv_seq_threads() { return HD <= 96 ? 768 : 512; }
 template <int HD, bool SEQ>
-__global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfma(AttnArgs p) {
+__global__ __launch_bounds__(SEQ ? dkv_seq_threads<HD>() : 256, SEQ ? (HD <= 96 ? 3 : 2) : 3) void attn_bwd_dkv_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     const int bh = xcd_logical(blockIdx.x, gridDim.x), b = bh / p.H, h = bh - b * p.H;
@@ -738,14 +749,19 @@ __global__ __launch_bounds__(SEQ ? 512 : 256, SEQ ? 2 : 3) void attn_bwd_dkv_mfm
             // the word holding field (key & 3) of the hash of query r, which quad lane r computed
             const uint32_t hwa[4] = {quad_bcast<0>(hq.a), quad_bcast<1>(hq.a), quad_bcast<2>(hq.a), quad_bcast<3>(hq.a)};
             const uint32_t hwb[4] = {quad_bcast<0>(hq.b), quad_bcast<1>(hq.b), quad_bcast<2>(hq.b), quad_bcast<3>(hq.b)};
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nl2[r]));
+            if (masked) {
+                masked_path();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = (qb + r >= qlo && qb + r < qhi) ? pv[r] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ql = qb + r;
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nl2[r]));
-                if (masked) pv = (ql >= qlo && ql < qhi) ? pv : 0.f;
                 const bool keep = ((((fsel & 2) ? hwb[r] : hwa[r]) >> fshift) & 0xFFFFu) >= p.drop_thr;
-                pf[t * 4 + r] = (bf16_t)(keep ? pv : 0.f);                    // 1/(1-p) is applied to the finished dV
-                dsf[t * 4 + r] = (bf16_t)(pv * ((keep ? dp[r] * p.drop_scale : 0.f) - dl4[r]));
+                pf[t * 4 + r] = (bf16_t)(keep ? pv[r] : 0.f);                 // 1/(1-p) is applied to the finished dV
+                dsf[t * 4 + r] = (bf16_t)(pv[r] * fmaf(keep ? dp[r] : 0.f, p.drop_scale, -dl4[r]));
             }
         }
 #pragma unroll
@@ -1179,7 +1195,7 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
         if (pl.seq_kv) {
             // many queries staged per workgroup: stage them once per (sequence, head) and walk every key tile
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, true>, lds_k);
-                        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, true>), dim3(a.B * a.H), dim3(512), lds_k, st, a));
+                        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, true>), dim3(a.B * a.H), dim3(dkv_seq_threads<HD>()), lds_k, st, a));
         } else {
             dim3 gk(a.B * a.H, pl.nyk);
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dkv_mfma<HD, false>, lds_k); hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, false>), gk, block, lds_k, st, a));

@@ -1719,7 +1719,13 @@ __global__ __launch_bounds__(256) void ce_ref_fixup_kernel(const int32_t* rowfla
                                                             const float* bias, int d, int V, bf16_t* probs, long ld, long prows,
                                                             float* rowref, float* lse, float* rowloss) {
     __shared__ float sm[4], ss[4];
-    // a workgroup looks after FIX_ROWS rows (normally none is flagged: the launch is 128 workgroups that read a flag each)
+    // a workgroup looks after FIX_ROWS rows; normally none is flagged, which one look at all its flags settles (walking them
+    // one dependent load after the other cost 10 us per launch)
+    {
+        const long mf = (long)blockIdx.x * FIX_ROWS + threadIdx.x;
+        const int flagged = (threadIdx.x < FIX_ROWS && mf < M) ? rowflag[mf] : 0;
+        if (!__syncthreads_or(flagged)) return;
+    }
     for (long m = (long)blockIdx.x * FIX_ROWS; m < min(M, ((long)blockIdx.x + 1) * FIX_ROWS); ++m) {
     if (!rowflag[m]) continue;
     __syncthreads();                                                  // the previous flagged row's shared sums are consumed

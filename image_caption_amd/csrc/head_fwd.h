@@ -34,6 +34,7 @@ struct HeadFwdArgs {
     long c_panel_rows;                   // modes 0 / 3: > 0: C is written as a column-panel image [ldc / 32][c_panel_rows][32] (ldc % 32 == 0)
     // filled by head_fwd_launch: bytes from one k-step's columns to the next, and by how much a view shrinks per k-step
     long kstepA, kstepB; int remdecA, remdecB;
+    int half_tiles;                      // set by the launchers: this many tiles of the last round are walked as two 256x128 halves
     int b_tr;                            // ppipe only: B is reduction-major [K, ldb] (the weight of a data gradient, read along its output index)
 };
 

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
     const int tm = (p.M + G::BMV - 1) / G::BMV, tn = (p.N + G::BNV - 1) / G::BNV;
     const int ntiles = tm * tn;
     const int nk = p.K / DBK;                               // whole 32-deep steps, at least NST of them (checked on the host)
+    // Half tiles (the standard and the residual epilogue on 256x256 tiles): when the tile count leaves a last round that at
+    // most half the workgroups would take, its tiles are cut into two 256x128 halves, one per workgroup (a wave then owns
+    // 128x32), so that round costs about half a tile's time instead of a whole one.  nfull tiles are walked as they are.
+    constexpr bool HALVES = (MODE == 1 || MODE == 2) && WM == 2 && WN == 4;
+    const int nfull = HALVES ? ntiles - p.half_tiles : ntiles;
 
     // what a lane fetches for its pieces of a stage: tile-independent
     unsigned offa[G::NJA], offb[G::NJB];
@@ -128,13 +133,21 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         offb[j] = (unsigned)(((long)row * p.ldb + kc * 8) * 2);
     }
     const int fragA = dlds(wr * G::WROWS + r16, q), fragB = G::A_BYTES + dlds(wc * 64 + r16, q);   // + 1024 per 16 rows
+    const int fragBh = G::A_BYTES + dlds(wc * 32 + r16, q);                                        // in a half tile
 
     int m0 = 0, n0 = 0;
+    // returns 0: past the last tile, 1: a whole tile, 2: a half tile (columns nn .. nn + 127)
     auto views_of = [&](int vb, View& va, View& vbv, int& mm, int& nn) {
-        if (vb < ntiles) {
+        int kind = vb < nfull ? 1 : 0, id = vb, hsel = 0;
+        if (HALVES && kind == 0 && vb < nfull + (int)gridDim.x) {
+            // the workgroups w and w + 8 (same XCD) share tile nfull + pair: the left and the right half
+            const int w = vb - nfull, pair = (w >> 4) * 8 + (w & 7);
+            if (pair < p.half_tiles) { kind = 2; id = nfull + pair; hsel = (w >> 3) & 1; }
+        }
+        if (kind) {
             int tile_m, tile_n;
-            map_tile(vb, tm, tn, tile_m, tile_n);
-            mm = tile_m * G::BMV; nn = tile_n * G::BNV;
+            map_tile(id, tm, tn, tile_m, tile_n);
+            mm = tile_m * G::BMV; nn = tile_n * G::BNV + hsel * 128;
             va.base = (const char*)(p.A + (long)mm * p.lda); va.rem = (long)(p.M - mm) * p.lda * 2;
             vbv.base = (const char*)(p.B + (long)nn * p.ldb); vbv.rem = (long)(p.N - nn) * p.ldb * 2;
         } else {                                          // past the last tile: loads that fetch nothing but still count
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             va.base = (const char*)p.A; va.rem = 0;
             vbv.base = (const char*)p.B; vbv.rem = 0;
         }
+        return kind;
     };
     auto issue_stage = [&](const View& va, const View& vbv, int k, int slot) {
         char* st = smem + slot * G::STAGE;
@@ -167,10 +181,10 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         }
     };
     // column constants of a tile from that slice: the bias, PAST beyond N
-    auto read_cb = [&](int nn, int sel, f32x4 (&cb)[4]) {
+    auto read_cb = [&](int nn, int sel, f32x4 (&cb)[4], int wcols) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = wc * 64 + j * 16 + 4 * q;
+            const int c = wc * wcols + j * 16 + 4 * q;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b = *reinterpret_cast<const f32x4*>(smem + G::RING + sel * G::BIAS_BYTES + c * 4);
 #pragma unroll
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
 
     int vb = blockIdx.x;
     View va, vbv, na, nbv;
-    views_of(vb, va, vbv, m0, n0);
+    int kind = views_of(vb, va, vbv, m0, n0);              // (a grid never starts on a half tile: those come after a whole round)
     unsigned long long t_start = 0, t_main = 0, t_epi = 0;
     if (STAMPS && tid == 0) t_start = __builtin_amdgcn_s_memtime();
     int bsel = 0;                                          // which of the two bias slices belongs to the current tile
@@ -198,7 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
 
     // one 32-deep step: wait for the stage, read its fragments, multiply, refill the slot read one step ago with
     // stage (rv, rk) -- of this tile or, in the last NST-1 steps, of the next one
-    auto step = [&](auto first, auto early, const View& rva, const View& rvb, int rk, int bias_nn, int ref_mm) {
+    auto step = [&](auto first, auto early, auto halfc, const View& rva, const View& rvb, int rk, int bias_nn, int ref_mm) {
+        constexpr int NJ = decltype(halfc)::value ? 2 : 4;          // 16-column blocks per wave
         // A tile's first NST-1 stages landed before the previous tile's epilogue stored anything (see there): no wait.
         // Later steps: all but the NST-2 youngest stages.  Stores may still be outstanding then; they only make this
         // wait stricter (loads complete in order among themselves), never laxer.
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         f32x4 cb[4];
         float rr[MODE == 3 ? TI : 1];
         if constexpr (decltype(first)::value) {
-            read_cb(n0, bsel, cb);
+            read_cb(n0, bsel, cb, NJ * 16);
             if constexpr (MODE == 3) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
         }
         bf16x8 af[TI], bfr[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + fragB + j * 1024);
+        for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + (NJ == 2 ? fragBh : fragB) + j * 1024);
 #pragma unroll
         for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + fragA + i * 1024);
         __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 // operands swapped: a lane then holds C[row = lane & 15][columns 4*(lane>>4) .. +3] of each 16x16 tile
                 if constexpr (decltype(first)::value) {
                     f32x4 c0 = cb[j];
@@ -260,21 +275,28 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
     for (;;) {
         const int vnext = vb + gridDim.x;
         int mn, nn;
-        views_of(vnext, na, nbv, mn, nn);
+        const int nkind = views_of(vnext, na, nbv, mn, nn);
         unsigned long long t0 = 0;
         if (STAMPS && tid == 0) t0 = __builtin_amdgcn_s_memtime();
         // ---- the tile's k-steps: the first NST-1 find their stages landed, the last NST-1 refill from the next tile
-        step(T{}, T{}, va, vbv, NST - 1, -1, 0);
+        auto k_steps = [&](auto halfc) {
+            step(T{}, T{}, halfc, va, vbv, NST - 1, -1, 0);
 #pragma unroll
-        for (int kt = 1; kt < NST - 1; ++kt) step(F{}, T{}, va, vbv, kt + NST - 1, -1, 0);
-        for (int kt = NST - 1; kt < nk - (NST - 1); ++kt) step(F{}, F{}, va, vbv, kt + NST - 1, -1, 0);
+            for (int kt = 1; kt < NST - 1; ++kt) step(F{}, T{}, halfc, va, vbv, kt + NST - 1, -1, 0);
+            for (int kt = NST - 1; kt < nk - (NST - 1); ++kt) step(F{}, F{}, halfc, va, vbv, kt + NST - 1, -1, 0);
 #pragma unroll
-        for (int s = 0; s < NST - 1; ++s) step(F{}, F{}, na, nbv, s, s == 0 ? nn : -1, mn);
+            for (int s = 0; s < NST - 1; ++s) step(F{}, F{}, halfc, na, nbv, s, s == 0 ? nn : -1, mn);
+        };
+        const bool half = HALVES && kind == 2;               // workgroup-uniform
+        if constexpr (HALVES) {
+            if (half) k_steps(T{}); else k_steps(F{});
+        } else k_steps(F{});
+        const int nj = half ? 2 : 4;                         // 16-column blocks of the wave's part of the tile
         unsigned long long t1 = 0;
         if (STAMPS && tid == 0) { t1 = __builtin_amdgcn_s_memtime(); t_main += t1 - t0; }
 
         // ---- epilogue on the accumulator registers
-        const int mw = m0 + wr * G::WROWS, nw = n0 + wc * 64;
+        const int mw = m0 + wr * G::WROWS, nw = n0 + wc * (half ? 32 : 64);
         const int slot = nw >> 6;
         // stores: one descriptor per 16-row block (scalar arithmetic), one lane offset for all of them; a lane whose row or
         // columns do not exist gets an offset no descriptor holds, and the store is dropped -- but always issued
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = (!HALVES || j < nj) ? acc[i][j][e] : 0.f;
             if constexpr (MODE == 2) {
                 // residual + dropout(z + bias) -> f32: the lane's 4 consecutive columns of each 16-column tile are one
                 // 16-byte load and one 16-byte store
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const __amdgpu_buffer_rsrc_t rr = rsrc_at((const char*)(p.residual + (long)mbb * p.ldr + nw), 0xFFFFFFF0L);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bool ok = r16 < p.M - mbb && 16 * j + 4 * q < p.N - nw;
+                        const bool ok = r16 < p.M - mbb && 16 * j + 4 * q < p.N - nw && j < nj;
                         const unsigned off = ok ? (unsigned)(((long)r16 * p.ldr + 16 * j + 4 * q) * 4) : 0xFFFFFFFFu;
                         dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
                     }
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                 if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's first stages have landed: see the prologue
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = row_ok && 16 * j + 4 * q < p.N - nw;
+                    const bool ok = row_ok && 16 * j + 4 * q < p.N - nw && j < nj;
                     const unsigned off = ok ? (unsigned)(((long)r16 * p.ldc + 16 * j + 4 * q) * 4) : 0xFFFFFFFFu;
                     const f32x4 o = {v[4 * j] + rv[j][0], v[4 * j + 1] + rv[j][1], v[4 * j + 2] + rv[j][2], v[4 * j + 3] + rv[j][3]};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
                     const unsigned y0 = pack_bf16(v[8 * jp + 4], v[8 * jp + 5]), y1 = pack_bf16(v[8 * jp + 6], v[8 * jp + 7]);
                     const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                     const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                    const bool ok = row_ok && colq + 32 * jp < p.store_cols - nw;
+                    const bool ok = row_ok && colq + 32 * jp < p.store_cols - nw && 2 * jp < nj;
                     const unsigned off = ok ? c_lane_off + c_pair_off * jp : 0xFFFFFFFFu;
                     // the numerators (0.8 GB that nothing reads before the backward products) leave as non-temporal
                     // stores: with the operands read as k-panel images that is 1.5 % faster inside the training step
@@ -416,8 +438,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Geo<WM, WN, TI, NST>::WG_PER_CU)) vo
             }
         }
         if (STAMPS && tid == 0) t_epi += __builtin_amdgcn_s_memtime() - t1;
-        if (vnext >= ntiles) break;
-        vb = vnext;
+        if (nkind == 0) break;
+        vb = vnext; kind = nkind;
         va = na; vbv = nbv; m0 = mn; n0 = nn;
         bsel ^= 1;
     }
@@ -436,6 +458,7 @@ struct LaunchTiming { bool on = false; int n = 0; hipEvent_t ev[2 * TIMING_PAIRS
 
 // diagnostic: k-panel images handed in beside the entry points' row-major operands (used when the sizes agree)
 int g_store_nt = 1;      // numerator stores non-temporal (diagnostic hook: 0 = write-back)
+int g_half_tiles = 1;    // the last round's tiles as halves (diagnostic hook: 0 = whole tiles only)
 struct PackedOverride { const bf16_t* Ap = nullptr; long a_rows = 0; const bf16_t* Bp = nullptr; long b_rows = 0; } g_packed;
 
 template <int WM, int WN, int TI, int NST>
@@ -452,6 +475,10 @@ int launch_geo(const HeadFwdArgs& a_in, hipStream_t st) {
     if (tiles <= 0) return CAPDEC_OK;
     long grid = 256L * G::WG_PER_CU;                      // every workgroup resident at once; a multiple of the 8 XCDs
     if (tiles < grid) grid = tiles;
+    // a last round of at most half the workgroups: its tiles go out as halves, one per workgroup (see the kernel)
+    a.half_tiles = 0;
+    if ((a.mode == 1 || a.mode == 2) && WM == 2 && WN == 4 && grid == 256 && g_half_tiles && tiles % 256 != 0 && tiles % 256 <= 128)
+        a.half_tiles = (int)(tiles % 256);
     auto go = [&](auto kfn) {
         ensure_dynamic_lds((const void*)kfn, 160 * 1024);      // once per (kernel, device)
         const bool timing = g_timing.on && g_timing.made && g_timing.n < TIMING_PAIRS && (a.mode == 0 || a.mode == 3) && a.C;      // the training forward only
@@ -474,6 +501,7 @@ int launch_geo(const HeadFwdArgs& a_in, hipStream_t st) {
 }  // namespace
 
 extern "C" void capdecdbg_head_fwd_store_nt(int on) { g_store_nt = on; }
+extern "C" void capdecdbg_head_fwd_half_tiles(int on) { g_half_tiles = on; }
 extern "C" void capdecdbg_head_fwd_packed(const void* Ap, long a_rows, const void* Bp, long b_rows) {
     g_packed = PackedOverride{(const bf16_t*)Ap, a_rows, (const bf16_t*)Bp, b_rows};
 }

@@ -121,7 +121,9 @@ def test_logits_ce_every_geometry(gemm_mode, mode):
     (515, 640, 768, True, 0.1, 0),            # ragged rows, several tiles
     (1000, 2056, 256, False, 0.0, 0),         # N a multiple of 8 only: the last tile's columns end inside a 64-column wave tile
     (300, 2304, 288, False, 0.2, 768),        # column scale on the first 768 columns (the query part of in_proj), 9 k-steps
-    (8192, 2304, 768, True, 0.1, 768),        # more tiles than workgroups
+    (8192, 2304, 768, True, 0.1, 768),        # more tiles than workgroups: 288, the last 32 walked as 64 halves of 256x128
+    (25500, 760, 256, True, 0.1, 0),          # 300 tiles, 44 as halves; ragged rows, and right halves that end inside a 32-column wave tile
+    (25600, 640, 256, False, 0.0, 0),         # ... right halves of the last tile column wholly past N
 ])
 @pytest.mark.parametrize("pmode", [10, 11, 12])       # 256x256 and 256x128 tiles of the ring kernel; the pipelined persistent kernel
 def test_persistent_standard_epilogue(gemm_mode, pmode, M, N, K, relu, p, scale_n):
@@ -162,6 +164,7 @@ def test_persistent_standard_epilogue(gemm_mode, pmode, M, N, K, relu, p, scale_
     (515, 768, 768, 0.1),            # out_proj shape: three column tiles, ragged rows
     (1000, 260, 2048, 0.0),          # N a multiple of 4 only, deep reduction (linear2)
     (8192, 768, 2048, 0.1),          # more tiles than workgroups
+    (25500, 760, 256, 0.1),          # 300 tiles of 256x256, the last 44 walked as halves; ragged rows and columns
 ])
 def test_persistent_residual_epilogue(gemm_mode, mode, M, N, K, p):
     """y = residual + dropout(x W^T + b) in f32 from the persistent kernel against the tile kernels and torch."""
