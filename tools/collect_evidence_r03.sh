@@ -20,4 +20,15 @@ O=gpurun_out
     echo "default:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1
     echo "--no-spans:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0 --no-spans 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1
   done; } > $O/r03_bench_brackets_ab.log
-tail -3 $O/r03_scaled_step_ab.log $O/r03_dp_bucket_timing.log $O/r03_bench_brackets_ab.log
+{ echo "# bench.py [--scaled-only] --stage-steps 0 [--no-half-tiles], alternating: one-block step, then the 12-block step";
+  C="--no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0"
+  for i in 1 2 3; do
+    echo "default:"; timeout -k 10 200 python bench.py $C 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+    echo "--no-half-tiles:"; timeout -k 10 200 python bench.py $C --no-half-tiles 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+  done
+  for i in 1 2 3; do
+    echo "scaled default:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+    echo "scaled --no-half-tiles:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 --no-half-tiles 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+  done; } > $O/r03_half_tiles_step_ab.log
+{ echo "# tools/attn_bench.py"; timeout -k 10 200 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_attention_microbench.log
+for f in $O/r03_scaled_step_ab.log $O/r03_dp_bucket_timing.log $O/r03_bench_brackets_ab.log; do tail -n 3 $f; done
