@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--greedy-images", type=int, default=4096)
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--no-ppipe", action="store_true", help="large data-gradient products on the tile kernels (A/B of the persistent pipelined kernel)")
+    ap.add_argument("--no-fused-attn-bwd", action="store_true",
+                    help="attention backward of the scored rows as a dQ kernel and a dK/dV kernel (A/B of the one-kernel form)")
     ap.add_argument("--no-half-tiles", action="store_true",
                     help="the persistent forward kernel walks whole 256x256 tiles only (A/B of the half tiles of its last round)")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="weight-gradient products on the compute stream (A/B of the second stream)")
@@ -327,6 +329,10 @@ def main():
         import ctypes
         from image_caption_amd import _lib
         _lib.load().capdecdbg_gemm_ppipe(ctypes.c_int(0))
+    if args.no_fused_attn_bwd:
+        import ctypes
+        from image_caption_amd import _lib
+        _lib.load().capdecdbg_attn_fused_bwd(ctypes.c_int(0))
     if args.no_half_tiles:
         import ctypes
         from image_caption_amd import _lib

@@ -800,6 +800,218 @@ __global__ __launch_bounds__(SEQ ? dkv_seq_threads<HD>() : 256, SEQ ? (HD <= 96 
     }
 }
 
+// ================================================================== backward, at most 32 queries: dQ, dK and dV in one kernel
+// The scored-rows case of the one-block model: 32 queries per (sequence, head) against all S keys.  The two kernels above
+// each read K and V of every head (the query-major one only to form 32 rows of dQ); here one workgroup of four waves per
+// (sequence, head) reads them once.  A wave takes 32 keys per pass (two 16-key tiles): per tile it forms S and dP for both
+// query tiles from K / V fragments that come straight from global memory (Q and dO of the 32 queries sit in LDS), dV and dK
+// of the tile as the key-major kernel does, and leaves the tile's K rows and dS in a wave-private LDS area; after the two
+// tiles the transposing reads of that area give K^T and dS^T, and dQ^T += K^T dS^T over the pass's 32 keys.  The waves'
+// partial dQ are summed at the end in wave order (through LDS: deterministic), delta = rowsum(dO * O) is formed on the way in.
+template <int HD> struct FusedGeo {
+    using G = Geo<HD>;
+    static constexpr int DSROWB = 32 * 2 + 16;                                  // a key's 32 dS values (bf16) + pad
+    static constexpr int QD_BYTES = 2 * 32 * G::ROWB + 2 * 32 * 4;              // Q, dO, -lse * log2(e), delta
+    static constexpr int WAVE_STAGE = 32 * G::ROWB + 32 * DSROWB;               // K rows and dS of the pass's 32 keys
+    static constexpr int EXCH_WAVE = 2 * G::DT * 64 * 16;                       // a wave's partial dQ: 2 query tiles x DT tiles x f32x4 per lane
+    static constexpr int AREA = 4 * WAVE_STAGE > 3 * EXCH_WAVE ? 4 * WAVE_STAGE : 3 * EXCH_WAVE;
+    static constexpr int LDS = QD_BYTES + AREA;
+};
+// transposed operand from a [row][col] bf16 image with row pitch PITCH: lane (g,i) gets { M[rA + 4g + 0..3][col0 + i], M[rB + 4g + 0..3][col0 + i] }
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_cols_pitch(const char* lds, int rA, int rB, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int off = (4 * g + (i >> 2)) * PITCH + (col0 + 4 * (i & 3)) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds + rA * PITCH + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds + rB * PITCH + off));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, HD <= 96 ? 3 : 2) void attn_bwd_fused32(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<HD>;
+    using F = FusedGeo<HD>;
+    const int bh = xcd_logical(blockIdx.x, gridDim.x), b = bh / p.H, h = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int nq = min(p.nq, p.S - p.q_start);                 // 1 .. 32
+    char* Ql = smem;
+    char* Dl = smem + 32 * G::ROWB;
+    float* lse_l = reinterpret_cast<float*>(smem + 2 * 32 * G::ROWB);
+    float* del_l = lse_l + 32;
+    char* area = smem + F::QD_BYTES;
+    char* Kst = area + wave * F::WAVE_STAGE;
+    char* dSst = Kst + 32 * G::ROWB;
+    const bf16_t* qbase = (const bf16_t*)p.q + b * p.q_bs + h * p.q_hs;
+    const bf16_t* dobase = (const bf16_t*)p.dout + b * p.do_bs + h * p.do_hs;
+    const bf16_t* kbase = (const bf16_t*)p.k + b * p.k_bs + h * p.k_hs;
+    const bf16_t* vbase = (const bf16_t*)p.v + b * p.v_bs + h * p.v_hs;
+    // K and V fragments of a 16-key tile, straight from memory (zero past S).  The first tile's are requested before the
+    // staging of Q and dO, every later tile's as soon as the S / dP products have consumed the previous ones.
+    bf16x8 kf[G::KS], vf[G::KS];
+    auto load_kv = [&](int kw) {
+        const int key = kw + i;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            kf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(kbase + (long)key * p.k_ss + ks * 32 + 8 * g) : zero_frag();
+            vf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(vbase + (long)key * p.v_ss + ks * 32 + 8 * g) : zero_frag();
+        }
+    };
+    load_kv(wave * 32);
+    rows_to_lds2<HD, 2>(Ql, qbase, p.q_ss, Dl, dobase, p.do_ss, p.q_start, nq, 32, tid, 256);
+    __syncthreads();
+    {
+        // delta = rowsum(dO * O): eight threads per query, each a few 16-byte chunks of the row (dO from LDS, O from memory)
+        const int ql = tid >> 3, part = tid & 7;
+        float dsum = 0.f;
+        if (ql < nq) {
+            const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * p.o_hs + (long)(p.q_start + ql) * p.o_ss;
+            for (int c = part; c < G::CPR; c += 8) {
+                const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + c * 8);
+                const bf16x8 df = *reinterpret_cast<const bf16x8*>(Dl + ql * G::ROWB + c * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dsum += (float)df[e] * (float)of[e];
+            }
+        }
+        dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+        if (part == 0) {
+            del_l[ql] = ql < nq ? dsum : 0.f;
+            lse_l[ql] = ql < nq ? -p.lse[(long)bh * p.S + p.q_start + ql] * ATT_LOG2E : 0.f;
+            if (ql < nq) p.delta[(long)bh * p.S + p.q_start + ql] = dsum;
+        }
+    }
+    __syncthreads();
+
+    f32x4 dqacc[2][G::DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) dqacc[qt][dt] = f32x4{0, 0, 0, 0};
+    const uint32_t grp_stride = (uint32_t)(p.S4 >> 2);
+    const uint32_t fsel = i & 3, fshift = (i & 1) * 16;
+
+    for (int kp = wave * 32; kp < p.S; kp += 128) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kw = kp + t * 16, key = kw + i;
+            const bool kok = key < p.S;
+            // the tile's K rows, for the transposing reads of the dQ products
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) *reinterpret_cast<bf16x8*>(Kst + (t * 16 + i) * G::ROWB + (ks * 32 + 8 * g) * 2) = kf[ks];
+            const bool open_key = p.mask_mode == CAPDEC_MASK_NONE || key < p.open_cols;
+            const int qlo = open_key ? 0 : max(0, key - p.q_start);
+            const int qhi = kok ? nq : 0;
+            const bool open_tile = p.mask_mode == CAPDEC_MASK_NONE || kw + 15 < p.open_cols;
+            const bool masked = !(open_tile || kw + 15 <= p.q_start) || nq < 32 || kw + 16 > p.S;        // wave-uniform
+            const uint32_t grp_key = (uint32_t)(key >> 2);
+            bf16x8 pf, dsf;
+            f32x4 s2[2], dp2[2];
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+                s2[tq] = f32x4{0, 0, 0, 0}; dp2[tq] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    s2[tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Ql, tq * 16, ks * 32, lane), kf[ks], s2[tq], 0, 0, 0);
+                    dp2[tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Dl, tq * 16, ks * 32, lane), vf[ks], dp2[tq], 0, 0, 0);
+                }
+            }
+            // the next tile's fragments replace the ones just consumed: the arithmetic and the products below cover their latency
+            {
+                const int nkw = t == 0 ? kw + 16 : kp + 128;
+                if (nkw < p.S) load_kv(nkw);
+            }
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+                const f32x4 s = s2[tq], dp = dp2[tq];
+                const int qb = tq * 16 + 4 * g;                // first of the lane's 4 local query rows
+                const f32x4 nl2 = *reinterpret_cast<const f32x4*>(lse_l + qb), dl4 = *reinterpret_cast<const f32x4*>(del_l + qb);
+                DropBits hq;
+                hq.a = hq.b = 0xFFFFFFFFu;
+                if (p.drop_thr) hq = dropout_hash4(p.drop_k0, p.drop_k1, (uint32_t)(bh * p.S + p.q_start + qb + (int)fsel) * grp_stride + grp_key);
+                const uint32_t hwa[4] = {quad_bcast<0>(hq.a), quad_bcast<1>(hq.a), quad_bcast<2>(hq.a), quad_bcast<3>(hq.a)};
+                const uint32_t hwb[4] = {quad_bcast<0>(hq.b), quad_bcast<1>(hq.b), quad_bcast<2>(hq.b), quad_bcast<3>(hq.b)};
+                float pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], ATT_LOG2E, nl2[r]));
+                if (masked) {
+                    masked_path();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = (qb + r >= qlo && qb + r < qhi) ? pv[r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = ((((fsel & 2) ? hwb[r] : hwa[r]) >> fshift) & 0xFFFFu) >= p.drop_thr;
+                    pf[tq * 4 + r] = (bf16_t)(keep ? pv[r] : 0.f);
+                    dsf[tq * 4 + r] = (bf16_t)(pv[r] * fmaf(keep ? dp[r] : 0.f, p.drop_scale, -dl4[r]));
+                }
+            }
+            // dS of (key i, queries 4g .. 4g+3 of either query tile) -> the wave's [key][query] image
+            {
+                const u32x4 du = __builtin_bit_cast(u32x4, dsf);
+                *reinterpret_cast<u32x2*>(dSst + (t * 16 + i) * F::DSROWB + (4 * g) * 2) = u32x2{du[0], du[1]};
+                *reinterpret_cast<u32x2*>(dSst + (t * 16 + i) * F::DSROWB + (16 + 4 * g) * 2) = u32x2{du[2], du[3]};
+            }
+            f32x4 dkacc[G::DT], dvacc[G::DT];
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(Dl, 0, 16, dt * 16, lane), pf, f32x4{0, 0, 0, 0}, 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(Ql, 0, 16, dt * 16, lane), dsf, f32x4{0, 0, 0, 0}, 0, 0, 0);
+            }
+            bf16_t* dkrow = (bf16_t*)p.dk + b * p.dk_bs + h * p.dk_hs + (long)key * p.dk_ss;
+            bf16_t* dvrow = (bf16_t*)p.dv + b * p.dv_bs + h * p.dv_hs + (long)key * p.dv_ss;
+            const int colq = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; dt += 2) {
+                const u32x4 dk8 = swap_pair(dkacc[dt], dkacc[dt + 1], 1.f), dv8 = swap_pair(dvacc[dt], dvacc[dt + 1], p.drop_scale);
+                if (kok) {
+                    *reinterpret_cast<u32x4*>(dkrow + dt * 16 + colq) = dk8;
+                    *reinterpret_cast<u32x4*>(dvrow + dt * 16 + colq) = dv8;
+                }
+            }
+        }
+        // dQ^T += K^T dS^T over the pass's 32 keys (the wave's own LDS area: written above by this wave only)
+        bf16x8 dst[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dst[qt] = frag_cols_pitch<F::DSROWB>(dSst, 0, 16, qt * 16, lane);
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+            const bf16x8 kt = frag_cols<HD>(Kst, 0, 16, dt * 16, lane);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dqacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dst[qt], dqacc[qt][dt], 0, 0, 0);
+        }
+    }
+    // ---- the waves' partial dQ, summed in wave order
+    __syncthreads();                                           // every wave is done with its staging area, which the exchange overlays
+    if (wave > 0) {
+        char* ex = area + (wave - 1) * F::EXCH_WAVE;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<f32x4*>(ex + ((qt * G::DT + dt) * 64 + lane) * 16) = dqacc[qt][dt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int ql = qt * 16 + i;
+            bf16_t* dqrow = (bf16_t*)p.dq + b * p.dq_bs + h * p.dq_hs + (long)(p.q_start + ql) * p.dq_ss;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                f32x4 a = dqacc[qt][dt];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) a += *reinterpret_cast<const f32x4*>(area + w * F::EXCH_WAVE + ((qt * G::DT + dt) * 64 + lane) * 16);
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(a[r] * p.dq_scale);
+                if (ql < nq) *reinterpret_cast<bf16x4*>(dqrow + dt * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
 // delta[bh][q] = sum_j do[q][j] * o[q][j]
 template <typename T>
 __global__ void attn_delta_kernel(AttnArgs p) {
@@ -1081,6 +1293,8 @@ void set_lds(K kernel, int bytes) {
 namespace { int g_attn_blocks = 1; }
 // diagnostic hook (not part of the declared ABI): 0 = forwards of at most 32 queries stage V whole, as longer ranges do
 extern "C" void capdecdbg_attn_block_staging(int on) { g_attn_blocks = on; }
+static int g_attn_fused = 1;      // at most 32 queries: dQ, dK, dV from one kernel (diagnostic hook: 0 = the two kernels)
+extern "C" void capdecdbg_attn_fused_bwd(int on) { g_attn_fused = on; }
 
 extern "C" int capdec_attn_fwd(const capdec_attn_desc* d, void* stream) {
     AttnArgs a;
@@ -1171,6 +1385,13 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
                      strides_ok8(a.dk_bs, a.dk_hs, a.dk_ss) && strides_ok8(a.dv_bs, a.dv_hs, a.dv_ss) &&
                      aligned16(a.dout) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv),
                      "attn_bwd(bf16): strides must be multiples of 8 elements and bases 16-byte aligned");
+        if (a.nq > 0 && a.nq <= 32 && !a.colsum_q && !a.colsum_kv && g_attn_fused) {
+            // the scored-rows case: one kernel for dQ, dK and dV (K and V of a head are read once)
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_fused32<HD>, FusedGeo<HD>::LDS);
+                        hipLaunchKernelGGL((attn_bwd_fused32<HD>), dim3(a.B * a.H), dim3(256), FusedGeo<HD>::LDS, st, a));
+            CAPDEC_LAUNCH_CHECK();
+            return CAPDEC_OK;
+        }
         const int SP = (a.S + 63) & ~63;
         const int lds_q = SP * (a.hd * 2 + 16);
         const int NQP = (a.nq + 31) & ~31;

@@ -1022,7 +1022,13 @@ def test_attention_query_range(dtype, tol, S, hd, nq):
         csq, cskv = torch.full((rq, d), float("nan"), device=DEV), torch.full((rk, 2 * d), float("nan"), device=DEV)
         dqkv2 = torch.zeros_like(qkv)
         ops.attn_bwd_packed(qkv, o, lse, dout, dqkv2, delta, B, H, S, hd, q_start=S - nq, nq=nq, colsum_q=csq, colsum_kv=cskv)
-        assert torch.equal(dqkv2, dqkv)
+        if nq > 32:
+            assert torch.equal(dqkv2, dqkv)
+        else:
+            # up to 32 queries the plain call runs the one-kernel backward and the call with column sums the two kernels:
+            # the same sums in another order (dQ over the waves' key ranges, delta over eight threads per row)
+            close(dqkv2, dqkv, 1e-2, "one-kernel backward vs the dQ and dK/dV kernels")
+            close(dqkv2, qr.grad, tol * 1.5, "dqkv (two kernels)")
         close(csq.sum(0), qr.grad[:, :d].sum(0), tol, "column sums of dq")
         close(cskv.sum(0), qr.grad[:, d:].sum(0), tol, "column sums of dk | dv")
 
