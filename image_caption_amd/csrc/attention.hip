@@ -10,7 +10,8 @@
 // are 16 contiguous bytes per lane and come straight from global memory, one key
 // block ahead of their use.  The backward uses the same trick twice: a
 // query-major kernel for dQ (K in LDS, V direct; it also produces delta = rowsum(dO*O))
-// and a key-major kernel for dK/dV, both recomputing P from the saved log-sum-exp.
+// and a key-major kernel for dK/dV, both recomputing P from the saved log-sum-exp; for at most 32 queries (the scored rows
+// of the one-block model) one kernel forms all three, so that K and V of a head cross the memory system once.
 // Validation (f32): simple exact-f32 kernels with the same interface.
 // Decoding: one query row against a contiguous K/V cache, HBM-bound.
 #include "common.h"
