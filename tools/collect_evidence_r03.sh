@@ -1,5 +1,7 @@
 #!/bin/bash
-# The A/B and yardstick logs of this round that DESIGN.md cites, in one call on one box (results in gpurun_out/; copy to profiles/).
+# A/B and yardstick logs collected in one call on one box: head power probe, vendor-library probe, block GEMM microbenchmark,
+# step A/Bs (persistent pipelined kernel, second stream, half tiles, event brackets), bucket timing, attention microbenchmark.
+# Results land in gpurun_out/ (copy to profiles/).
 #   bash tools/collect_evidence_r03.sh
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
@@ -30,5 +32,15 @@ O=gpurun_out
     echo "scaled default:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
     echo "scaled --no-half-tiles:"; timeout -k 10 200 python bench.py --scaled-only --stage-steps 0 --no-half-tiles 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
   done; } > $O/r03_half_tiles_step_ab.log
+{ echo "# bench.py --stage-steps 0 [--no-fused-attn-bwd], alternating: one-block step at batch 256 (ms per step), then the fixed-global-batch-2048 leg (samples/s)";
+  C="--no-greedy --no-cpu-baseline --no-scaled --no-global-2048 --no-yardstick --stage-steps 0"
+  for i in 1 2 3; do
+    echo "default:"; timeout -k 10 200 python bench.py $C 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+    echo "--no-fused-attn-bwd:"; timeout -k 10 200 python bench.py $C --no-fused-attn-bwd 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+  done
+  for i in 1 2; do
+    echo "global 2048, default:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-yardstick --stage-steps 0 2>/dev/null | grep -o '"global_2048": {"value": [0-9.]*'
+    echo "global 2048, --no-fused-attn-bwd:"; timeout -k 10 200 python bench.py --no-greedy --no-cpu-baseline --no-scaled --no-yardstick --stage-steps 0 --no-fused-attn-bwd 2>/dev/null | grep -o '"global_2048": {"value": [0-9.]*'
+  done; } > $O/r03_fused_attn_bwd_ab.log
 { echo "# tools/attn_bench.py"; timeout -k 10 200 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_attention_microbench.log
 for f in $O/r03_scaled_step_ab.log $O/r03_dp_bucket_timing.log $O/r03_bench_brackets_ab.log; do tail -n 3 $f; done
