@@ -197,6 +197,10 @@ def load():
     got = lib.capdec_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"libcapdec ABI {got} != binding ABI {ABI_VERSION}: rebuild the library")
+    if os.environ.get("CAPDEC_ATTN_LEAN_DQ") and hasattr(lib, "capdecdbg_attn_lean_dq"):                # diagnostic
+        lib.capdecdbg_attn_lean_dq.argtypes = [c_int]
+        lib.capdecdbg_attn_lean_dq.restype = None
+        lib.capdecdbg_attn_lean_dq(int(os.environ["CAPDEC_ATTN_LEAN_DQ"]))
     if os.environ.get("CAPDEC_HEAD_FWD_STORE_NT") and hasattr(lib, "capdecdbg_head_fwd_store_nt"):      # diagnostic
         lib.capdecdbg_head_fwd_store_nt.argtypes = [c_int]
         lib.capdecdbg_head_fwd_store_nt.restype = None

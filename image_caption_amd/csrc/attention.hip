@@ -516,8 +516,12 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : 3) vo
 // BLK = 1 or 2 (waves per workgroup; at most 32 queries, SEQ = false): K staged in 64-key blocks by LDS-DMA, double
 // buffered, as V is in the forward.  The next block is requested after the current block's last LDS read (the compiler
 // drains outstanding LDS-DMA before any LDS read it cannot tell apart from the DMA's target).
-template <int HD, bool SEQ, int BLK = 0>
-__global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK ? 2 : 3)) void attn_bwd_dq_mfma(AttnArgs p) {
+// LEAN (SEQ only, head width up to 96): sixteen waves per workgroup and no register look-ahead -- the fragments are read from
+// LDS where they are used, which leaves 128 registers per wave, so four waves per SIMD cover each other's LDS and exp
+// latencies and the head's 19 query tiles take two passes instead of three (dQ at S = 290: 250 -> 222 us; twelve waves
+// measured level with eight; the same squeeze on the dK/dV kernel spills inside its loop and loses 40 us).
+template <int HD, bool SEQ, int BLK = 0, bool LEAN = false>
+__global__ __launch_bounds__(SEQ ? (LEAN ? 1024 : 512) : (BLK ? 64 * BLK : 256), SEQ ? (LEAN ? 4 : 1) : (BLK ? 2 : 3)) void attn_bwd_dq_mfma(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<HD>;
     static_assert(!(SEQ && BLK), "block staging belongs to the slab form");
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
             vfr[set][ks] = frag_rows<HD>(Vl, key0, ks * 32, lane);
         }
     };
-    if constexpr (SEQ) read_rows(0, 0);
+    if constexpr (SEQ && !LEAN) read_rows(0, 0);
     for (int kb = 0; kb < SP; kb += 64) {
         const char* Kb = BLK ? Kl + ((kb >> 6) & 1) * 64 * G::ROWB : Kl + kb * G::ROWB;
         if constexpr (BLK != 0) {
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 s = f32x4{0, 0, 0, 0}, dp = f32x4{0, 0, 0, 0};
-            if constexpr (SEQ) {
+            if constexpr (SEQ && !LEAN) {
                 if (t < 3) read_rows(kb + (t + 1) * 16, (t + 1) & 1);
                 else if (kb + 64 < SP) read_rows(kb + 64, 0);
                 if (t == 2) {
@@ -618,9 +622,12 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
             }
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                if constexpr (SEQ) {
+                if constexpr (SEQ && !LEAN) {
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[t & 1][ks], qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[t & 1][ks], dof[ks], dp, 0, 0, 0);
+                } else if constexpr (SEQ) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kb, t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Vl, kb + t * 16, ks * 32, lane), dof[ks], dp, 0, 0, 0);
                 } else {
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(Kb, t * 16, ks * 32, lane), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][ks], dof[ks], dp, 0, 0, 0);
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(SEQ ? 512 : (BLK ? 64 * BLK : 256), SEQ ? 1 : (BLK 
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int dt = 0; dt < G::DT; ++dt) {
-                if constexpr (SEQ) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf[st][dt], dsf[st], acc[dt], 0, 0, 0);
+                if constexpr (SEQ && !LEAN) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcf[st][dt], dsf[st], acc[dt], 0, 0, 0);
                 else acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         frag_cols<HD>(Kb, (2 * st) * 16, (2 * st + 1) * 16, dt * 16, lane), dsf[st], acc[dt], 0, 0, 0);
             }
@@ -1294,6 +1301,8 @@ void set_lds(K kernel, int bytes) {
 namespace { int g_attn_blocks = 1; }
 // diagnostic hook (not part of the declared ABI): 0 = forwards of at most 32 queries stage V whole, as longer ranges do
 extern "C" void capdecdbg_attn_block_staging(int on) { g_attn_blocks = on; }
+static int g_attn_lean_dq = 1;    // whole-sequence dQ kernel with 12 waves and no register look-ahead (diagnostic hook: 0 = 8 waves with look-ahead)
+extern "C" void capdecdbg_attn_lean_dq(int on) { g_attn_lean_dq = on; }
 static int g_attn_fused = 1;      // at most 32 queries: dQ, dK, dV from one kernel (diagnostic hook: 0 = the two kernels)
 extern "C" void capdecdbg_attn_fused_bwd(int on) { g_attn_fused = on; }
 
@@ -1399,7 +1408,10 @@ extern "C" int capdec_attn_bwd(const capdec_attn_bwd_desc* d, void* stream) {
         const int lds_k = 2 * NQP * (a.hd * 2 + 16) + 2 * NQP * 4;
         CAPDEC_CHECK(lds_q <= 160 * 1024 && lds_k <= 160 * 1024, "attn_bwd(bf16): sequence %d too long for the LDS-resident design (hd=%d)", a.S, a.hd);
         dim3 block(256);
-        if (pl.seq_q) {
+        if (pl.seq_q && g_attn_lean_dq && a.hd <= 96) {
+            HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, true, 0, true>, 2 * lds_q);
+                        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, true, 0, true>), dim3(a.B * a.H), dim3(1024), 2 * lds_q, st, a));
+        } else if (pl.seq_q) {
             HD_DISPATCH(a.hd, set_lds(attn_bwd_dq_mfma<HD, true>, 2 * lds_q);
                         hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, true>), dim3(a.B * a.H), dim3(512), 2 * lds_q, st, a));
         } else if (a.nq > 0) {
