@@ -1033,6 +1033,56 @@ def test_attention_query_range(dtype, tol, S, hd, nq):
         close(cskv.sum(0), qr.grad[:, d:].sum(0), tol, "column sums of dk | dv")
 
 
+@pytest.mark.parametrize("B,H,S,hd,nq,mode,prefix,p", [
+    (3, 2, 229, 96, 32, _lib.MASK_PREFIX_CAUSAL, 198, 0.1),     # the one-block model's scored rows under the prefix-causal mask
+    (2, 3, 130, 64, 17, _lib.MASK_PREFIX_CAUSAL, 100, 0.2),     # a ragged second query tile, a ragged last key tile
+    (5, 1, 40, 128, 32, _lib.MASK_NONE, 0, 0.1),                # fewer keys than one pass of the four waves; S < q_start + 32 never happens: nq <= S
+    (2, 2, 290, 96, 32, _lib.MASK_REFERENCE, 0, 0.0),           # the last block of the stacked model
+    (1, 4, 20, 32, 20, _lib.MASK_PREFIX_CAUSAL, 0, 0.0),        # every query scored, purely causal
+])
+def test_attention_backward_one_kernel(B, H, S, hd, nq, mode, prefix, p):
+    """At most 32 scored queries: dQ, dK and dV from one kernel (the default) against torch and against the dQ + dK/dV
+    pair (capdecdbg_attn_fused_bwd(0)), under masks and dropout; twice in a row (identical bits: the waves' partial dQ are
+    summed in a fixed order)."""
+    import ctypes
+    lib = _lib.load()
+    lib.capdecdbg_attn_fused_bwd.argtypes = [ctypes.c_int]
+    lib.capdecdbg_attn_fused_bwd.restype = None
+    d = H * hd
+    q0 = S - nq
+    qkv = rnd(S * B, 3 * d, dtype=torch.bfloat16, scale=0.7, seed=36)
+    drop = ops.dropout_keys(3, 1, 5, p=p)
+    keep = ops.attn_dropout_mask(drop, B, H, S, DEV) if p > 0 else None
+    o = torch.zeros(S * B, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H * S, device=DEV)
+    ops.attn_fwd_packed(qkv, o, lse, B, H, S, hd, q_start=q0, nq=nq, mask_mode=mode, prefix_len=prefix, drop=drop)
+    qr = qkv.float().requires_grad_(True)
+    oref, _ = torch_attention(qr, B, H, S, hd, mask_for(S, mode, prefix), keep, p)
+    dout = rnd(S * B, d, dtype=torch.bfloat16, seed=37)
+    dout[:q0 * B] = 0
+    oref.backward(dout.float())
+    outs, deltas = [], []
+    for fused in (1, 1, 0):
+        dqkv = torch.zeros_like(qkv)
+        delta = torch.zeros(B * H * S, device=DEV)
+        lib.capdecdbg_attn_fused_bwd(fused)
+        try:
+            ops.attn_bwd_packed(qkv, o, lse, dout, dqkv, delta, B, H, S, hd, q_start=q0, nq=nq, mask_mode=mode, prefix_len=prefix, drop=drop,
+                                dq_scale=0.5)
+        finally:
+            lib.capdecdbg_attn_fused_bwd(1)
+        outs.append(dqkv.float())
+        deltas.append(delta)
+    want = qr.grad.clone()
+    want[:, :d] *= 0.5
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], want, 3e-2, "one kernel vs torch")
+    close(outs[0], outs[2], 1e-2, "one kernel vs the dQ and dK/dV kernels")
+    close(deltas[0], deltas[2], 1e-3, "delta")
+    if q0 > 0:
+        assert outs[0][:q0 * B, :d].abs().max().item() == 0        # rows that are not scored receive no dQ
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
 @pytest.mark.parametrize("H,hd,smax,length", [(8, 96, 229, 229), (2, 32, 21, 14), (3, 64, 290, 257), (2, 128, 40, 1)])
 def test_attention_decode(dtype, tol, H, hd, smax, length):
